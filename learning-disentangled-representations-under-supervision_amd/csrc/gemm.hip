@@ -1,0 +1,416 @@
+// fp32 MFMA GEMM for gfx950: C = epilogue(alpha * A·B + beta*C + bias), exact-fp32 v_mfma_f32_32x32x2_f32.
+//
+// Design (MI355X_MICROARCH: the f32 MFMA runs at the f32 vector rate, 64 cycles per 32x32x2 per SIMD, so the loop
+// is MFMA-paced and LDS/global staging only has to stay out of the way):
+//   * square block tile BT x BT (128 or 64), BK = 32, 256 threads = 4 waves in a 2x2 grid, each wave owns
+//     (BT/2)x(BT/2) outputs as (BT/64)^2 accumulators of 32x32;
+//   * operands are staged global -> registers -> LDS in a k-major [BK][BT+1] image: the MFMA fragment read
+//     (lane l: row l&31 of k-slice l>>5) is then 32 consecutive floats per half-wave = bank-conflict free;
+//   * the next K tile's global loads are issued before the current tile's MFMAs (register prefetch);
+//   * two-level addressing on every operand axis (see cgn_hip.h) covers transposed operands, overlapping conv
+//     windows and [B,T+1,H] history buffers without copies;
+//   * tall-K / few-tile problems are split along K into fp32 slabs, summed in fixed order by a second kernel
+//     (bitwise reproducible, no float atomics);
+//   * blockIdx -> tile mapping is XCD-aware: blocks that share an XCD (blockIdx % 8) walk neighbouring tiles.
+#include "common.h"
+
+namespace {
+
+struct Axis {
+    long stride, rpg, gs;
+};
+
+__device__ __forceinline__ long axis_off(const Axis& a, long i) {
+    if (a.rpg > 0) {
+        const long g = i / a.rpg;
+        return g * a.gs + (i - g * a.rpg) * a.stride;
+    }
+    return i * a.stride;
+}
+
+struct GemmParams {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias0;
+    const float* bias1;
+    const float* a_row_param;
+    const float* ep_logits;
+    const float* ep_lse;
+    const float* ep_rowdot;
+    const int64_t* ep_target;
+    float* ws;
+    long ldc, ep_ld;
+    Axis am, ak, bk, bn;
+    int M, N, K;
+    int k_per_split, splitk;
+    int a_vec, b_vec;
+    int a_transform, epilogue;
+    int tiles_m, tiles_n;
+    float alpha, beta, a_scale, ep_inv_tau, ep_ce_scale;
+};
+
+constexpr int BK = 32;
+constexpr int NT = 256;
+
+__device__ __forceinline__ float apply_epilogue(const GemmParams& p, int row, int col, float acc) {
+    if (p.epilogue == CGN_EPI_SOFTMAX_BWD) {
+        const float pr = expf(p.ep_logits[(long)row * p.ep_ld + col] * p.ep_inv_tau - p.ep_lse[row]);
+        const float onehot = (p.ep_target[row] == (int64_t)col) ? 1.f : 0.f;
+        return pr * (acc - p.ep_rowdot[row]) * p.ep_inv_tau + p.ep_ce_scale * (pr - onehot);
+    }
+    float v = p.alpha * acc;
+    if (p.bias0) v += p.bias0[col];
+    if (p.bias1) v += p.bias1[col];
+    if (p.beta != 0.f) v += p.beta * p.C[(long)row * p.ldc + col];
+    return v;
+}
+
+// Operand tile loader. The tile is ROWS (m or n index) x BK (k index).
+//   KC = true : memory is contiguous along k (row-major [rows][k])  -> lanes run along k, float4 along k
+//   KC = false: memory is contiguous along the row index ([k][rows]) -> lanes run along rows, float4 along rows
+template <int ROWS, bool KC>
+struct TileLoader {
+    static constexpr int QUADS = ROWS * BK / 4;  // float4 chunks per tile
+    static constexpr int PER = QUADS / NT;       // chunks per thread
+    static_assert(QUADS % NT == 0, "tile/threads mismatch");
+
+    f32x4 regs[PER];
+    long roff[KC ? PER : 4];  // KC: per-chunk row offsets; !KC: offsets of the 4 rows of this thread's quad
+    bool rok[KC ? PER : 4];
+    float rparam[KC ? PER : 1];
+
+    __device__ __forceinline__ void init(const Axis& ar, int r0, int rlimit, int transform, const float* row_param) {
+        const int tid = threadIdx.x;
+        if constexpr (KC) {
+            constexpr int QPR = BK / 4;   // quads per row
+            constexpr int RS = NT / QPR;  // row step between a thread's chunks
+            const int r = tid / QPR;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int row = r0 + r + i * RS;
+                rok[i] = row < rlimit;
+                roff[i] = rok[i] ? axis_off(ar, row) : 0;
+                rparam[i] = (transform && rok[i]) ? row_param[row] : 0.f;
+            }
+        } else {
+            constexpr int QPK = ROWS / 4;  // quads per k
+            const int rq = tid % QPK;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = r0 + rq * 4 + j;
+                rok[j] = row < rlimit;
+                roff[j] = rok[j] ? axis_off(ar, row) : 0;
+            }
+            rparam[0] = 0.f;
+        }
+    }
+
+    // Issue the global loads of the tile whose first k is k0 (k valid in [k0, kend)).
+    __device__ __forceinline__ void load(const float* __restrict__ base, const Axis& ak, int k0, int kend, bool vec,
+                                         int transform, float scale) {
+        const int tid = threadIdx.x;
+        if constexpr (KC) {
+            constexpr int QPR = BK / 4;
+            const int q = tid % QPR;
+            const int k = k0 + q * 4;
+            long koff[4];
+            if (vec) {
+                koff[0] = axis_off(ak, k);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) koff[j] = axis_off(ak, k + j);
+            }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (rok[i]) {
+                    if (vec && k + 3 < kend) {
+                        v = *reinterpret_cast<const f32x4*>(base + roff[i] + koff[0]);
+                    } else if (vec) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (k + j < kend) v[j] = base[roff[i] + koff[0] + j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (k + j < kend) v[j] = base[roff[i] + koff[j]];
+                    }
+                    if (transform == CGN_ATRANS_EXP) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = (k + j < kend) ? expf(v[j] * scale - rparam[i]) : 0.f;
+                    }
+                }
+                regs[i] = v;
+            }
+        } else {
+            constexpr int QPK = ROWS / 4;
+            constexpr int KS = NT / QPK;
+            const int kr = tid / QPK;
+            const bool all_ok = rok[3];  // rows are increasing: last valid => all valid
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int k = k0 + kr + i * KS;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k < kend) {
+                    const long koff = axis_off(ak, k);
+                    if (vec && all_ok) {
+                        v = *reinterpret_cast<const f32x4*>(base + roff[0] + koff);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (rok[j]) v[j] = base[roff[j] + koff];
+                    }
+                }
+                regs[i] = v;
+            }
+        }
+    }
+
+    // Write the staged registers into the k-major LDS image dst[BK][ROWS + 1].
+    __device__ __forceinline__ void store(float* __restrict__ dst) const {
+        constexpr int LD = ROWS + 1;
+        const int tid = threadIdx.x;
+        if constexpr (KC) {
+            constexpr int QPR = BK / 4;
+            constexpr int RS = NT / QPR;
+            const int q = tid % QPR;
+            const int r = tid / QPR;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[(q * 4 + j) * LD + r + i * RS] = regs[i][j];
+            }
+        } else {
+            constexpr int QPK = ROWS / 4;
+            constexpr int KS = NT / QPK;
+            const int rq = tid % QPK;
+            const int kr = tid / QPK;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[(kr + i * KS) * LD + rq * 4 + j] = regs[i][j];
+            }
+        }
+    }
+};
+
+// XCD-aware bijective remap: blocks with equal (bid % 8) share an XCD's L2 (observed round-robin dispatch), so
+// give each of the 8 residue classes one contiguous chunk of the tile list.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg / 8, r = nwg % 8;
+    const int xcd = bid % 8, idx = bid / 8;
+    const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
+}
+
+template <int BT, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(NT) void gemm_kernel(const GemmParams p) {
+    constexpr int TW = BT / 64;  // 32x32 accumulators per wave along each dim
+    constexpr int LD = BT + 1;
+    __shared__ float As[BK * LD];
+    __shared__ float Bs[BK * LD];
+
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    // m fastest: neighbouring tiles share the B (usually the weight) panel
+    const int tile_m = t % p.tiles_m;
+    const int tile_n = t / p.tiles_m;
+    const int m0 = tile_m * BT, n0 = tile_n * BT;
+
+    const int kbeg = blockIdx.y * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    TileLoader<BT, A_KC> la;
+    TileLoader<BT, B_KC> lb;
+    la.init(p.am, m0, p.M, p.a_transform, p.a_row_param);
+    lb.init(p.bn, n0, p.N, 0, nullptr);
+
+    f32x16 acc[TW][TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+#pragma unroll
+        for (int j = 0; j < TW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        la.load(p.A, p.ak, kbeg, kend, p.a_vec, p.a_transform, p.a_scale);
+        lb.load(p.B, p.bk, kbeg, kend, p.b_vec, 0, 0.f);
+        la.store(As);
+        lb.store(Bs);
+    }
+    __syncthreads();
+
+    const int fr = lane & 31;  // fragment row/col
+    const int fk = lane >> 5;  // k-slice within the 32x32x2 step
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) {
+            const int k0 = kbeg + (kt + 1) * BK;
+            la.load(p.A, p.ak, k0, kend, p.a_vec, p.a_transform, p.a_scale);
+            lb.load(p.B, p.bk, k0, kend, p.b_vec, 0, 0.f);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TW], b[TW];
+#pragma unroll
+            for (int i = 0; i < TW; ++i) a[i] = As[(kk * 2 + fk) * LD + wm * (BT / 2) + i * 32 + fr];
+#pragma unroll
+            for (int j = 0; j < TW; ++j) b[j] = Bs[(kk * 2 + fk) * LD + wn * (BT / 2) + j * 32 + fr];
+#pragma unroll
+            for (int i = 0; i < TW; ++i)
+#pragma unroll
+                for (int j = 0; j < TW; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            la.store(As);
+            lb.store(Bs);
+            __syncthreads();
+        }
+    }
+
+    // Epilogue. C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+            const int col = n0 + wn * (BT / 2) + j * 32 + fr;
+            if (col >= p.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (row >= p.M) continue;
+                if (p.splitk > 1) {
+                    p.ws[((long)blockIdx.y * p.M + row) * p.N + col] = acc[i][j][r];
+                } else {
+                    p.C[(long)row * p.ldc + col] = apply_epilogue(p, row, col, acc[i][j][r]);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
+    const long total = (long)p.M * p.N;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < p.splitk; ++z) s += p.ws[(long)z * total + idx];
+        const int row = (int)(idx / p.N), col = (int)(idx % p.N);
+        p.C[(long)row * p.ldc + col] = apply_epilogue(p, row, col, s);
+    }
+}
+
+bool axis_vec_ok(const cgn_axis& contig, const cgn_axis& other) {
+    if (contig.stride != 1) return false;
+    if (contig.rpg != 0 && (contig.rpg % 4 != 0 || contig.gs % 4 != 0)) return false;
+    if (other.stride % 4 != 0) return false;
+    if (other.rpg != 0 && other.gs % 4 != 0) return false;
+    return true;
+}
+
+template <int BT>
+void launch(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
+    if (a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_kernel<BT, true, true>), grid, dim3(NT), 0, s, p);
+    else if (a_kc && !b_kc)
+        hipLaunchKernelGGL((gemm_kernel<BT, true, false>), grid, dim3(NT), 0, s, p);
+    else if (!a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_kernel<BT, false, true>), grid, dim3(NT), 0, s, p);
+    else
+        hipLaunchKernelGGL((gemm_kernel<BT, false, false>), grid, dim3(NT), 0, s, p);
+}
+
+}  // namespace
+
+extern "C" int cgn_abi_version(void) { return 1; }
+
+extern "C" int cgn_gemm_f32(void* stream, const cgn_gemm_desc* d) {
+    CGN_CHECK_ARG(d != nullptr);
+    CGN_CHECK_ARG(d->M >= 0 && d->N >= 0 && d->K >= 0);
+    if (d->M == 0 || d->N == 0) return CGN_OK;
+    CGN_CHECK_ARG(d->A && d->B && d->C);
+    CGN_CHECK_ARG(d->ldc >= d->N);
+    CGN_CHECK_ARG(d->a_transform == CGN_ATRANS_NONE || (d->a_transform == CGN_ATRANS_EXP && d->a_row_param));
+    CGN_CHECK_ARG(d->epilogue == CGN_EPI_LINEAR || d->epilogue == CGN_EPI_SOFTMAX_BWD);
+    if (d->epilogue == CGN_EPI_SOFTMAX_BWD)
+        CGN_CHECK_ARG(d->ep_logits && d->ep_lse && d->ep_rowdot && d->ep_target && d->ep_ld >= d->N);
+    CGN_CHECK_ARG(d->force_tile == 0 || d->force_tile == 64 || d->force_tile == 128);
+    // an operand is "k-contiguous" when its k stride is 1; otherwise lanes run along its row index
+    const bool a_kc = d->a_k.stride == 1 || d->a_m.stride != 1;
+    const bool b_kc = d->b_k.stride == 1 || d->b_n.stride != 1;
+    CGN_CHECK_ARG(d->a_transform == CGN_ATRANS_NONE || a_kc);
+
+    GemmParams p;
+    p.A = d->A; p.B = d->B; p.C = d->C;
+    p.bias0 = d->bias0; p.bias1 = d->bias1; p.a_row_param = d->a_row_param;
+    p.ep_logits = d->ep_logits; p.ep_lse = d->ep_lse; p.ep_rowdot = d->ep_rowdot; p.ep_target = d->ep_target;
+    p.ldc = d->ldc; p.ep_ld = d->ep_ld;
+    p.am = {d->a_m.stride, d->a_m.rpg, d->a_m.gs};
+    p.ak = {d->a_k.stride, d->a_k.rpg, d->a_k.gs};
+    p.bk = {d->b_k.stride, d->b_k.rpg, d->b_k.gs};
+    p.bn = {d->b_n.stride, d->b_n.rpg, d->b_n.gs};
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.a_transform = d->a_transform; p.epilogue = d->epilogue;
+    p.alpha = d->alpha; p.beta = d->beta; p.a_scale = d->a_scale;
+    p.ep_inv_tau = d->ep_inv_tau; p.ep_ce_scale = d->ep_ce_scale;
+    p.a_vec = ((uintptr_t)d->A % 16 == 0) && (a_kc ? axis_vec_ok(d->a_k, d->a_m) : axis_vec_ok(d->a_m, d->a_k));
+    p.b_vec = ((uintptr_t)d->B % 16 == 0) && (b_kc ? axis_vec_ok(d->b_k, d->b_n) : axis_vec_ok(d->b_n, d->b_k));
+
+    // Tile / split-K heuristic: MI355X has 256 CUs and this kernel fits ~4 blocks per CU; aim for >= ~512 blocks.
+    int bt = d->force_tile;
+    if (bt == 0) {
+        const long t128 = (long)cgn_cdiv(d->M, 128) * cgn_cdiv(d->N, 128);
+        bt = (t128 >= 384) ? 128 : 64;
+    }
+    p.tiles_m = cgn_cdiv(d->M, bt);
+    p.tiles_n = cgn_cdiv(d->N, bt);
+    const long tiles = (long)p.tiles_m * p.tiles_n;
+    int splitk = d->force_splitk;
+    if (splitk <= 0) {
+        splitk = 1;
+        if (tiles < 256 && d->K >= 256) {
+            splitk = (int)((768 + tiles - 1) / tiles);
+            const int max_by_k = d->K / 128;  // keep >= 128 of K per split
+            if (splitk > max_by_k) splitk = max_by_k;
+            if (splitk < 1) splitk = 1;
+        }
+    }
+    if (splitk > 1) {
+        const long need = (long)splitk * d->M * d->N * (long)sizeof(float);
+        if (!d->workspace || d->workspace_bytes < need) {
+            if (d->force_splitk > 0) return CGN_ERR_WORKSPACE;
+            const long fit = d->workspace ? d->workspace_bytes / ((long)d->M * d->N * (long)sizeof(float)) : 0;
+            splitk = fit >= 2 ? (int)fit : 1;
+        }
+    }
+    int kps = cgn_cdiv(cgn_cdiv(d->K, splitk), BK) * BK;
+    if (kps < BK) kps = BK;
+    splitk = d->K > 0 ? cgn_cdiv(d->K, kps) : 1;
+    p.k_per_split = kps;
+    p.splitk = splitk;
+    p.ws = d->workspace;
+
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)tiles, (unsigned)splitk);
+    if (bt == 128)
+        launch<128>(p, a_kc, b_kc, grid, s);
+    else
+        launch<64>(p, a_kc, b_kc, grid, s);
+    CGN_LAUNCH_CHECK();
+    if (splitk > 1) {
+        const long total = (long)d->M * d->N;
+        int blocks = cgn_cdiv(total, 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
+        CGN_LAUNCH_CHECK();
+    }
+    return CGN_OK;
+}

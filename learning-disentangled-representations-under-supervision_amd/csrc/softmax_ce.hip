@@ -1,0 +1,102 @@
+// Temperature softmax + NLL over [M, V] logits (model/cgn.py:1086-1092 of the reference).
+// HBM-bound: one streaming read of the logits (16 B/lane), online max/sum per thread, block reduce per row.
+#include "common.h"
+
+namespace {
+
+constexpr int SM_NT = 256;
+
+__device__ __forceinline__ void online_update(float& m, float& s, float x) {
+    if (x > m) {
+        s = s * expf(m - x) + 1.f;
+        m = x;
+    } else {
+        s += expf(x - m);
+    }
+}
+
+__global__ __launch_bounds__(SM_NT) void softmax_nll_fwd_kernel(const float* __restrict__ logits, long ld,
+                                                                const int64_t* __restrict__ target, int V,
+                                                                float inv_tau, float* __restrict__ lse,
+                                                                float* __restrict__ nll) {
+    __shared__ float red_m[SM_NT / 64];
+    __shared__ float red_s[SM_NT / 64];
+    const int row = blockIdx.x;
+    const float* x = logits + (long)row * ld;
+    float m = -INFINITY, s = 0.f;
+    const bool vec = ((uintptr_t)x % 16 == 0);
+    if (vec) {
+        const int nv = V / 4;
+        const f32x4* xv = reinterpret_cast<const f32x4*>(x);
+        for (int i = threadIdx.x; i < nv; i += SM_NT) {
+            const f32x4 v = xv[i];
+            // one max per quad keeps the expf count at 4 (+1 on a new maximum)
+            const float q0 = v[0] * inv_tau, q1 = v[1] * inv_tau, q2 = v[2] * inv_tau, q3 = v[3] * inv_tau;
+            const float qm = fmaxf(fmaxf(q0, q1), fmaxf(q2, q3));
+            if (qm > m) {
+                s *= expf(m - qm);
+                m = qm;
+            }
+            s += expf(q0 - m) + expf(q1 - m) + expf(q2 - m) + expf(q3 - m);
+        }
+        for (int i = nv * 4 + threadIdx.x; i < V; i += SM_NT) online_update(m, s, x[i] * inv_tau);
+    } else {
+        for (int i = threadIdx.x; i < V; i += SM_NT) online_update(m, s, x[i] * inv_tau);
+    }
+    // wave reduce of (m, s) pairs
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o, 64);
+        const float s2 = __shfl_xor(s, o, 64);
+        const float mn = fmaxf(m, m2);
+        const float e1 = (m == -INFINITY) ? 0.f : expf(m - mn);
+        const float e2 = (m2 == -INFINITY) ? 0.f : expf(m2 - mn);
+        s = s * e1 + s2 * e2;
+        m = mn;
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red_m[w] = m;
+        red_s[w] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float mm = red_m[0];
+#pragma unroll
+        for (int i = 1; i < SM_NT / 64; ++i) mm = fmaxf(mm, red_m[i]);
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < SM_NT / 64; ++i) ss += (red_m[i] == -INFINITY) ? 0.f : red_s[i] * expf(red_m[i] - mm);
+        const float l = mm + logf(ss);
+        lse[row] = l;
+        const int64_t tg = target[row];
+        // an out-of-range target yields NaN instead of an out-of-bounds read
+        nll[row] = (tg >= 0 && tg < V) ? l - x[tg] * inv_tau : NAN;
+    }
+}
+
+// Deterministic mean of n floats: single block, fixed order.
+__global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, int n, float scale,
+                                                   float* __restrict__ out) {
+    __shared__ float red[8];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+    s = block_sum<256>(s, red);
+    if (threadIdx.x == 0) out[0] = s * scale;
+}
+
+}  // namespace
+
+extern "C" int cgn_softmax_nll_fwd_f32(void* stream, const float* logits, int64_t ld, const int64_t* target, int32_t M,
+                                       int32_t V, float inv_tau, float* lse, float* nll, float* loss) {
+    CGN_CHECK_ARG(M >= 0 && V > 0 && ld >= V);
+    if (M == 0) return CGN_OK;
+    CGN_CHECK_ARG(logits && target && lse && nll && loss);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(softmax_nll_fwd_kernel, dim3(M), dim3(SM_NT), 0, s, logits, (long)ld, target, V, inv_tau, lse,
+                       nll);
+    CGN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, nll, M, 1.0f / (float)M, loss);
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}

@@ -1,0 +1,84 @@
+"""ctypes binding of libcgn_hip.so (the C-ABI declared in include/cgn_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a symbol is absent, importing the ops or
+calling them raises. The product path never routes through torch ops or the CPU oracle.
+"""
+import ctypes as C
+import os
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG_DIR, "lib", "libcgn_hip.so")
+
+CGN_OK = 0
+CGN_ERR_INVALID_ARG = 1
+CGN_ERR_WORKSPACE = 2
+CGN_ERR_HIP_BASE = 1000
+
+ATRANS_NONE = 0
+ATRANS_EXP = 1
+EPI_LINEAR = 0
+EPI_SOFTMAX_BWD = 1
+
+c_float_p = C.c_void_p  # raw device pointers travel as integers
+c_i64 = C.c_int64
+c_i32 = C.c_int32
+c_f32 = C.c_float
+c_ptr = C.c_void_p
+
+
+class Axis(C.Structure):
+    _fields_ = [("stride", c_i64), ("rpg", c_i64), ("gs", c_i64)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", c_ptr), ("B", c_ptr), ("C", c_ptr),
+        ("bias0", c_ptr), ("bias1", c_ptr), ("a_row_param", c_ptr),
+        ("ep_logits", c_ptr), ("ep_lse", c_ptr), ("ep_rowdot", c_ptr), ("ep_target", c_ptr),
+        ("workspace", c_ptr), ("workspace_bytes", c_i64),
+        ("ldc", c_i64), ("ep_ld", c_i64),
+        ("a_m", Axis), ("a_k", Axis), ("b_k", Axis), ("b_n", Axis),
+        ("M", c_i32), ("N", c_i32), ("K", c_i32),
+        ("a_transform", c_i32), ("epilogue", c_i32),
+        ("alpha", c_f32), ("beta", c_f32), ("a_scale", c_f32),
+        ("ep_inv_tau", c_f32), ("ep_ce_scale", c_f32),
+        ("force_tile", c_i32), ("force_splitk", c_i32),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/cgn_hip.h one to one (tests check the header against this table)
+PROTOTYPES = {
+    "cgn_abi_version": (c_i32, []),
+    "cgn_gemm_f32": (c_i32, [c_ptr, C.POINTER(GemmDesc)]),
+    "cgn_softmax_nll_fwd_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_i32, c_f32, c_ptr, c_ptr, c_ptr]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and attach prototypes. Raises if it is missing: no fallback exists."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libcgn_hip.so not found at %s. Build it with `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the CGN hot path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc == CGN_OK:
+        return
+    if rc == CGN_ERR_INVALID_ARG:
+        raise RuntimeError("%s: invalid argument (shape/alignment/null pointer)" % what)
+    if rc == CGN_ERR_WORKSPACE:
+        raise RuntimeError("%s: workspace too small" % what)
+    raise RuntimeError("%s: HIP error %d" % (what, rc - CGN_ERR_HIP_BASE))

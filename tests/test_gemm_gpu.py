@@ -1,0 +1,158 @@
+"""GPU parity of the fp32 MFMA GEMM (C-ABI cgn_gemm_f32) against fp64 CPU matmul.
+
+Tolerance: the kernel is an exact-fp32 FMA chain, so |err| <= ~K * eps * sum|a*b|; we check a relative Frobenius
+error <= 2e-6 and exactness on small-integer operands (which also catches any fragment-layout transposition,
+since the operands are asymmetric).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    import ldrs_amd  # noqa: F401
+    from ldrs_amd.hip import ops
+    return ops
+
+
+def _rel(a, ref):
+    return (a.double().cpu() - ref).norm().item() / max(ref.norm().item(), 1e-30)
+
+
+def _mk(shape, gen, ints=False):
+    if ints:
+        return torch.randint(-3, 4, shape, generator=gen).float()
+    return torch.randn(shape, generator=gen)
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 300, 96), (128, 128, 32), (1, 1, 1), (65, 129, 825), (257, 70, 365),
+                                   (64, 64, 1024), (33, 2048, 512)])
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt"])
+@pytest.mark.parametrize("tile", [0, 64, 128])
+def test_gemm_layouts(dev, M, N, K, layout, tile):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 131 + N * 17 + K)
+    ints = (M + N + K) % 2 == 0
+    A = _mk((M, K), g, ints)
+    B = _mk((K, N), g, ints)
+    ref = A.double() @ B.double()
+    if layout[0] == "n":
+        a = A.to(dev)
+    else:
+        a = A.t().contiguous().to(dev).t()
+    if layout[1] == "n":
+        b = B.to(dev)
+    else:
+        b = B.t().contiguous().to(dev).t()
+    out = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(a, b, out, force_tile=tile)
+    if ints:
+        assert torch.equal(out.cpu().double(), ref)
+    else:
+        assert _rel(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("splitk", [2, 5])
+def test_gemm_splitk_bias_beta(dev, splitk):
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    M, N, K = 150, 90, 1000
+    A, B = _mk((M, K), g), _mk((K, N), g)
+    C0, b0, b1 = _mk((M, N), g), _mk((N,), g), _mk((N,), g)
+    ref = 0.5 * (A.double() @ B.double()) + 2.0 * C0.double() + b0.double() + b1.double()
+    out = C0.to(dev).clone()
+    ops.gemm(A.to(dev), B.to(dev), out, alpha=0.5, beta=2.0, bias0=b0.to(dev), bias1=b1.to(dev),
+             force_splitk=splitk)
+    assert _rel(out, ref) < 2e-6
+    # same through the heuristic path, into a strided output view
+    big = torch.zeros(M, N + 13, device=dev)
+    view = big[:, 5:5 + N]
+    view.copy_(C0.to(dev))
+    ops.gemm(A.to(dev), B.to(dev), view, alpha=0.5, beta=2.0, bias0=b0.to(dev), bias1=b1.to(dev))
+    assert _rel(view, ref) < 2e-6
+    assert big[:, :5].abs().max().item() == 0 and big[:, 5 + N:].abs().max().item() == 0
+
+
+def test_gemm_conv_windows(dev):
+    """Text-CNN as implicit GEMM: row (b,t) of A is the contiguous window x[b, t:t+Kw, :] (discriminator_sentiment.py:64)."""
+    ops = _ops()
+    from ldrs_amd.hip._lib import Axis
+    g = torch.Generator().manual_seed(3)
+    Bn, Lx, L, E, Kw, Co = 5, 9, 8, 12, 3, 7
+    x = _mk((Bn, Lx, E), g)
+    W = _mk((Co, 1, Kw, E), g)
+    bias = _mk((Co,), g)
+    ref = torch.nn.functional.conv2d(x[:, :L].double().unsqueeze(1), W.double(), bias.double()).squeeze(3)  # [B,Co,L-Kw+1]
+    ref = ref.permute(0, 2, 1).reshape(Bn * (L - Kw + 1), Co)
+    xd, Wd = x.to(dev), W.to(dev)
+    out = torch.empty(Bn * (L - Kw + 1), Co, device=dev)
+    ops.gemm(xd, Wd.view(Co, Kw * E).t(), out, M=Bn * (L - Kw + 1), K=Kw * E,
+             a_m=Axis(E, L - Kw + 1, Lx * E), a_k=Axis(1, 0, 0), bias0=bias.to(dev))
+    assert _rel(out, ref) < 2e-6
+
+
+def test_gemm_history_buffer_tn(dev):
+    """dW_hh = dGates^T · h_prev with h_prev = hbuf[:, :T] of a [B, T+1, H] buffer (K axis two-level on B)."""
+    ops = _ops()
+    from ldrs_amd.hip._lib import Axis
+    g = torch.Generator().manual_seed(4)
+    Bn, T, H = 6, 5, 16
+    dg = _mk((Bn, T, 4 * H), g)
+    hbuf = _mk((Bn, T + 1, H), g)
+    ref = dg.double().reshape(Bn * T, 4 * H).t() @ hbuf[:, :T].double().reshape(Bn * T, H)
+    out = torch.empty(4 * H, H, device=dev)
+    ops.gemm(dg.to(dev).view(Bn * T, 4 * H).t(), hbuf.to(dev), out, N=H, K=Bn * T,
+             b_k=Axis(H, T, (T + 1) * H), b_n=Axis(1, 0, 0))
+    assert _rel(out, ref) < 2e-6
+
+
+def test_gemm_softmax_operand_and_backward_epilogue(dev):
+    """soft-embedding fwd (A = exp(logits/tau - lse) on the fly) and the fused dlogits epilogue (cgn.py:1086-1108)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    M, V, E = 70, 333, 24
+    tau = 0.9
+    logits = (_mk((M, V), g) * 3).double().requires_grad_(True)
+    emb = _mk((V, E), g).double()
+    target = torch.randint(0, V, (M,), generator=g)
+    dout = _mk((M, E), g).double()
+    ls = torch.log_softmax(logits / tau, dim=1)
+    ce = torch.nn.functional.nll_loss(ls, target) * 79
+    soft = torch.exp(ls) @ emb
+    (ce + (soft * dout).sum()).backward()
+    ref_soft, ref_dlogits = soft.detach(), logits.grad
+
+    lg = logits.detach().float().to(dev)
+    embd = emb.float().to(dev)
+    tg = target.to(dev)
+    lse, nll, loss = ops.softmax_nll_fwd(lg, tg, 1.0 / tau)
+    assert abs(loss.item() * 79 - ce.item()) / abs(ce.item()) < 1e-6
+    out = torch.empty(M, E, device=dev)
+    ops.gemm(lg, embd, out, a_exp=(1.0 / tau, lse))
+    assert _rel(out, ref_soft) < 2e-6
+    dod = dout.float().to(dev)
+    rowdot = (dod * out).sum(1).contiguous()
+    dlogits = torch.empty(M, V, device=dev)
+    ops.gemm(dod, embd.t(), dlogits, softmax_bwd=dict(logits=lg, lse=lse, rowdot=rowdot, target=tg,
+                                                     inv_tau=1.0 / tau, ce_scale=79.0 / (M * tau)))
+    assert _rel(dlogits, ref_dlogits) < 5e-6
+    # in place over the logits (what the training step does to save 107 MB at cfg2)
+    lg2 = lg.clone()
+    ops.gemm(dod, embd.t(), lg2, softmax_bwd=dict(logits=lg2, lse=lse, rowdot=rowdot, target=tg,
+                                                 inv_tau=1.0 / tau, ce_scale=79.0 / (M * tau)))
+    assert torch.equal(lg2, dlogits)
+
+
+def test_gemm_rejects_bad_args(dev):
+    ops = _ops()
+    a = torch.zeros(4, 8, device=dev)
+    b = torch.zeros(9, 4, device=dev)
+    with pytest.raises(ValueError):
+        ops.gemm(a, b, torch.zeros(4, 4, device=dev))
+    with pytest.raises(TypeError):
+        ops.gemm(a.cpu(), b, torch.zeros(4, 4, device=dev))
+    from ldrs_amd.hip._lib import Axis
+    with pytest.raises(ValueError):  # window addressing that would run past the buffer
+        ops.gemm(a, torch.zeros(16, 4, device=dev), torch.zeros(8, 4, device=dev), M=8, K=16,
+                 a_m=Axis(8, 0, 0), a_k=Axis(1, 0, 0))
