@@ -95,6 +95,130 @@ int cgn_gemm_f32(void* stream, const cgn_gemm_desc* desc /* host */);
 int cgn_softmax_nll_fwd_f32(void* stream, const float* logits, int64_t ld, const int64_t* target, int32_t M, int32_t V,
                             float inv_tau, float* lse, float* nll, float* loss);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * LSTM recurrence (nn.LSTM at model/encoder.py:17-21,40 and model/generator.py:17-20,58). The input projections
+ * x·W_ihᵀ + b_ih + b_hh are cgn_gemm_f32 calls; these entry points run the T dependent steps (one launch per step,
+ * up to 4 independent sequences — e.g. the encoder's two directions — per launch). Layouts (batch-major fp32):
+ *   xg [B,T,4H] gate order i,f,g,o · hbuf/cbuf [B,T+1,H]: forward sequences keep the initial state in slot 0 and
+ *   the state after time t in slot t+1; reverse sequences keep the initial state in slot T and time t in slot t ·
+ *   gates [B,T,4H] activated gates (saved for backward). The caller initialises the initial-state slots. H % 4 == 0.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct cgn_lstm_fwd_seq {
+    const float* xg;
+    const float* xg_extra; /* nullable [B,4H]: added at every timestep (the tiled [z,c] input, generator.py:54-56) */
+    const float* w_hh;     /* [4H,H] */
+    float* hbuf;
+    float* cbuf;
+    float* gates;
+    int32_t reverse;
+} cgn_lstm_fwd_seq;
+
+int cgn_lstm_seq_fwd_f32(void* stream, const cgn_lstm_fwd_seq* seqs /* host */, int32_t nseq, int32_t B, int32_t T,
+                         int32_t H);
+
+/* BPTT. dgates [B,T,4H] receives d(pre-activation gates); dW_ih/dW_hh/db/dX follow as GEMMs / column sums.
+ * dh_ext: nullable gradient wrt the emitted h, element (b,t,j) at dh_ext[b*dh_bs + t*dh_ts + j];
+ * dh_seed: nullable [B,H] gradient wrt the final hidden state; dc_state [B,H]: in = gradient wrt the final cell
+ * state (the encoder's context, encoder.py:43-46), out = gradient wrt the initial cell state. */
+typedef struct cgn_lstm_bwd_seq {
+    const float* w_hh_t; /* [H,4H] = W_hhᵀ (cgn_transpose_f32) */
+    const float* cbuf;
+    const float* gates;
+    const float* dh_ext;
+    const float* dh_seed;
+    float* dgates;
+    float* dc_state;
+    int64_t dh_bs, dh_ts;
+    int32_t reverse;
+} cgn_lstm_bwd_seq;
+
+int cgn_lstm_seq_bwd_f32(void* stream, const cgn_lstm_bwd_seq* seqs /* host */, int32_t nseq, int32_t B, int32_t T,
+                         int32_t H);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Convolution + max-over-time pooling helpers, shared by the text-CNN discriminator
+ * (model/discriminator_sentiment.py:56-78; act = 0 ReLU, weight layout 0 = [Co][K][E]) and the char-TDNN
+ * (selfModules/tdnn.py:40-43; act = 1 tanh, weight layout 1 = [od][Cc][kW]). The convolution product itself is
+ * cgn_gemm_f32 over overlapping windows.
+ * ---------------------------------------------------------------------------------------------------------- */
+#define CGN_ACT_RELU 0
+#define CGN_ACT_TANH 1
+typedef struct cgn_conv_widths {
+    const float* W[8]; /* per width: weights */
+    float* dW[8];      /* per width: weight gradient (cgn_conv_bwd_dw_f32) */
+    float* db[8];      /* per width: bias gradient, nullable (TDNN has no bias) */
+    int32_t K[8];      /* window length */
+    int32_t Co[8];     /* maps of this width */
+    int32_t col0[8];   /* first feature column of this width in the pooled feature row */
+    int32_t n;         /* number of widths (<= 8) */
+    int32_t F;         /* pooled feature row length (sum of Co) */
+    int32_t act, layout;
+} cgn_conv_widths;
+
+/* conv [B*P, Co] (row (b,p), bias included) -> feat[b, col0+co] = act(max_p conv), arg = argmax position
+ * (-1 where the ReLU gate is closed). */
+int cgn_act_maxpool_f32(void* stream, const float* conv, int32_t B, int32_t P, int32_t Co, int32_t act, float* feat,
+                        int64_t ldf, int32_t col0, int32_t* arg, int64_t lda);
+/* dX[b, 0:L, 0:E] (sentence stride sent_stride) from dfeat [B,F] through the kept windows; feat needed for tanh. */
+int cgn_conv_bwd_dx_f32(void* stream, const cgn_conv_widths* widths /* host */, const float* dfeat, const float* feat,
+                        const int32_t* arg, int32_t B, int32_t L, int32_t E, float* dx, int64_t sent_stride);
+/* dW/db (+= when beta = 1) from dfeat through the kept windows of x [B, L, E]. */
+int cgn_conv_bwd_dw_f32(void* stream, const cgn_conv_widths* widths /* host */, const float* dfeat, const float* feat,
+                        const int32_t* arg, const float* x, int64_t sent_stride, int32_t B, int32_t L, int32_t E,
+                        float beta);
+/* Embedding-table gradient (char_embed, selfModules/embedding.py:45 backward): dtable[v,:] = beta*dtable[v,:] +
+ * sum_{pos: idx[pos]==v} dx[pos,:]; atomics-free, fixed order. */
+int cgn_embedding_bwd_f32(void* stream, const int64_t* idx, const float* dx, int32_t n, int32_t V, int32_t E, float beta,
+                          float* dtable);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Streaming glue kernels.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* dst[r,c] = scale*src[r,c] + beta*dst[r,c] (strided rows). */
+int cgn_copy2d_f32(void* stream, const float* src, int64_t lds, float* dst, int64_t ldd, int32_t rows, int32_t cols,
+                   float scale, float beta);
+/* dst[cols, rows] = src[rows, cols]ᵀ (dense). */
+int cgn_transpose_f32(void* stream, const float* src, int32_t rows, int32_t cols, float* dst);
+/* out[i, 0:E] = table[idx[i], :] * mask[i, :] (nn.Embedding lookups of the frozen word table,
+ * selfModules/embedding.py:42,57; mask = explicit word-dropout mask, model/generator.py:52; nullable). */
+int cgn_gather_rows_f32(void* stream, const float* table, int32_t V, int32_t E, const int64_t* idx, int32_t n,
+                        const float* mask, float* out, int64_t ldo);
+/* Highway gate (selfModules/highway.py:38-44). pre = [N, 3S]: [nonlinear | linear | gate] pre-activations. */
+int cgn_highway_gate_fwd_f32(void* stream, const float* pre, int32_t N, int32_t S, float* out, int64_t ldo);
+int cgn_highway_gate_bwd_f32(void* stream, const float* pre, int32_t N, int32_t S, const float* dy, int64_t ldy,
+                             float* dpre);
+/* Reparameterisation + KLD (model/cgn.py:94-101,1076-1080). mulv [B,2Z] = [mu|logvar]; zc [B,Z+C] = [z|c]. */
+int cgn_reparam_kld_fwd_f32(void* stream, const float* mulv, const float* eps, const float* c, int32_t B, int32_t Z,
+                            int32_t C, float* zc, float* stdv, float* kld);
+/* dmulv = d/d[mu|logvar] of (g·z + kld_weight*B*kld), g = dL/dz (nullable, row stride ldg), kld_weight = kld_coef/B. */
+int cgn_reparam_kld_bwd_f32(void* stream, const float* mulv, const float* eps, const float* g, int64_t ldg,
+                            float kld_weight, int32_t B, int32_t Z, float* dmulv);
+/* out[c] = beta*out[c] + sum_r x[r,c] (bias gradients); workspace >= 64*C floats. */
+int cgn_colsum_f32(void* stream, const float* x, int64_t ld, int32_t R, int32_t C, float beta, float* out,
+                   float* workspace, int64_t workspace_bytes);
+/* out[b,c] = sum_t x[b,t,c]. */
+int cgn_sum_time_f32(void* stream, const float* x, int32_t B, int32_t T, int32_t C, float* out);
+/* out[r] = sum_c a[r,c]*b[r,c]. */
+int cgn_rowdot_f32(void* stream, const float* a, int64_t lda, const float* b, int64_t ldb, int32_t R, int32_t C,
+                   float* out);
+/* torch.optim.Adam defaults (model/cgn.py:267,1046-1047) over a flat parameter arena; g is read as g*grad_scale
+ * (1/world_size after a sum all-reduce). step >= 1 is the step count AFTER this update. */
+int cgn_adam_f32(void* stream, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                 float beta2, float eps, int32_t step, float grad_scale);
+/* 2-class head (discriminator_sentiment.py:76-77 + losses of cgn.py:167-170,306,318-334,1118):
+ * logits = (feat*mask)·Wᵀ + b; stats = {mean CE(y), mean entropy}; p1 = softmax[:,1];
+ * dlogits = d(w_ce*CE + w_ent*entropy)/dlogits. mask, y, p1, dlogits, stats nullable. */
+int cgn_disc_head_f32(void* stream, const float* feat, int64_t ldf, const float* mask, const float* W, const float* bias,
+                      const int64_t* y, int32_t B, int32_t F, float w_ce, float w_ent, float* logits, float* p1,
+                      float* dlogits, float* stats);
+int cgn_disc_head_bwd_f32(void* stream, const float* feat, int64_t ldf, const float* mask, const float* W,
+                          const float* dlogits, int32_t B, int32_t F, float beta, float* dW, float* db, float* dfeat);
+/* c = (u < p1) — t.bernoulli(softmax[:,1]) with the uniform draw given (model/cgn.py:170). */
+int cgn_bernoulli_f32(void* stream, const float* p1, const float* u, int32_t n, float* c);
+int cgn_fill_f32(void* stream, float* p, int64_t n, float v);
+/* out[0] = sum_i coef[i]*src[i][0], n <= 4 (loss totals of model/cgn.py:329,334,1151-1152); src, coef: host arrays. */
+int cgn_lincomb_f32(void* stream, int32_t n, const float* const* src, const float* coef, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,269 @@
+// Multi-width 1-D convolution + max-over-time pooling around the implicit-GEMM convolution, for both users:
+//   * the text-CNN discriminator (model/discriminator_sentiment.py:56-78): Conv2d(1,Co,(K,E)) + ReLU + max-pool,
+//     weights [Co][K][E] (layout 0), one "sentence" = [L, E] word embeddings;
+//   * the char-TDNN (selfModules/tdnn.py:40-43): conv1d(no bias) + tanh + max over positions, weights [od][Cc][kW]
+//     (torch conv1d layout = layout 1), one "sentence" = one word = [W, Cc] char embeddings.
+// The convolution itself is cgn_gemm_f32 over overlapping windows (two-level A addressing; for layout 1 also a
+// two-level K axis on the weight operand). Here: activation + pooling with argmax, and the two backward routes through
+// the pooled maximum. Max-over-time keeps ONE position per (sentence, map), so both backward routes are sparse
+// (one K*E window per map) and run on the VALU with thread-exclusive accumulators (fixed summation order).
+#include "common.h"
+
+namespace {
+
+constexpr int ACT_RELU = 0, ACT_TANH = 1;
+
+// conv is [B*P, Co] (row (b,p)), bias included. feat[b, col0+co] = act(max_p conv); arg = argmax position, or -1 when
+// the ReLU gate is closed (max <= 0: no gradient).
+__global__ __launch_bounds__(256) void act_maxpool_kernel(const float* __restrict__ conv, int B, int P, int Co, int act,
+                                                          float* __restrict__ feat, long ldf, int col0,
+                                                          int32_t* __restrict__ arg, long lda) {
+    const long total = (long)B * Co;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / Co), co = (int)(i % Co);
+        const float* p = conv + (long)b * P * Co + co;
+        float best = p[0];
+        int bi = 0;
+        for (int t = 1; t < P; ++t) {
+            const float v = p[(long)t * Co];
+            if (v > best) {
+                best = v;
+                bi = t;
+            }
+        }
+        if (act == ACT_TANH) {
+            feat[(long)b * ldf + col0 + co] = tanhf(best);  // tanh is monotonic: max tanh(x) = tanh(max x)
+            arg[(long)b * lda + col0 + co] = bi;
+        } else {
+            feat[(long)b * ldf + col0 + co] = fmaxf(best, 0.f);
+            arg[(long)b * lda + col0 + co] = (best > 0.f) ? bi : -1;
+        }
+    }
+}
+
+constexpr int MAXW = 8;
+struct ConvWidths {
+    const float* W[MAXW];
+    float* dW[MAXW];
+    float* db[MAXW];
+    int K[MAXW], Co[MAXW], col0[MAXW];
+    int n, F, act, layout;
+};
+
+__device__ __forceinline__ float pooled_grad(const ConvWidths& w, const float* dfeat, const float* feat, long idx) {
+    float g = dfeat[idx];
+    if (w.act == ACT_TANH) {
+        const float y = feat[idx];
+        g *= (1.f - y * y);
+    }
+    return g;
+}
+
+// dX[b, t, e] = sum over (width, map) whose kept window covers t of g[b,map] * W[map][t - t0][e].
+// One wave owns 64 consecutive outputs (t,e) of one sentence (e fastest => coalesced weight reads) and walks all
+// maps; the (argmax, gradient) pairs of 64 maps are loaded one per lane and broadcast with v_readlane, so the inner
+// loop has no dependent global loads. Every output element is owned by exactly one lane: no atomics, fixed order.
+__global__ __launch_bounds__(256) void conv_bwd_dx_kernel(const ConvWidths w, const float* __restrict__ dfeat,
+                                                          const float* __restrict__ feat,
+                                                          const int32_t* __restrict__ arg, int L, int E,
+                                                          float* __restrict__ dx, long sent_stride) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int o = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;  // output index within the sentence
+    const bool live = o < L * E;
+    const int t = live ? o / E : 0, e = live ? o % E : 0;
+    // wave-uniform bounds on t (lanes are consecutive outputs)
+    const int o_first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (o_first >= L * E) return;
+    const int t_lo = o_first / E, t_hi = min(L * E - 1, o_first + 63) / E;
+    float acc = 0.f;
+    for (int wi = 0; wi < w.n; ++wi) {
+        const int Kw = w.K[wi], Co = w.Co[wi];
+        const float* Wb = w.W[wi];
+        for (int c0 = 0; c0 < Co; c0 += 64) {
+            int my_t0 = -1;
+            float my_g = 0.f;
+            if (c0 + lane < Co) {
+                const long fi = (long)b * w.F + w.col0[wi] + c0 + lane;
+                my_t0 = arg[fi];
+                if (my_t0 >= 0 && my_t0 + Kw <= L) my_g = pooled_grad(w, dfeat, feat, fi);
+                else my_t0 = -1;
+            }
+            const int nc = min(64, Co - c0);
+            for (int c = 0; c < nc; ++c) {
+                const int t0 = __builtin_amdgcn_readlane(my_t0, c);
+                if (t0 < 0 || t0 > t_hi || t0 + Kw <= t_lo) continue;  // scalar branch: window misses this wave
+                const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_g), c));
+                const int k = t - t0;
+                if (live && k >= 0 && k < Kw) {
+                    const float* wr = Wb + (long)(c0 + c) * Kw * E;
+                    acc += g * ((w.layout == 0) ? wr[k * E + e] : wr[e * Kw + k]);
+                }
+            }
+        }
+    }
+    if (live) dx[(long)b * sent_stride + o] = acc;
+}
+
+// dW[map][window element] (+)= sum_b g[b,map] * x[b, t0(b,map) + k, e];  db[map] (+)= sum_b g[b,map].
+// Workgroup = 64 window elements of one map; its 4 waves split the batch four ways and are summed through LDS in
+// fixed order. (t0, g) of 64 sentences are loaded one per lane and broadcast, so x loads pipeline freely.
+__global__ __launch_bounds__(256) void conv_bwd_dw_kernel(const ConvWidths w, const float* __restrict__ dfeat,
+                                                          const float* __restrict__ feat, const int32_t* __restrict__ arg,
+                                                          const float* __restrict__ x, long sent_stride, int B, int L,
+                                                          int E, float beta) {
+    __shared__ float red[4][64];
+    __shared__ float redb[4];
+    const int wi = blockIdx.z, co = blockIdx.y;
+    const int Kw = w.K[wi];
+    const int KE = Kw * E;
+    if (co >= w.Co[wi] || blockIdx.x * 64 >= KE) return;  // uniform per block
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;  // window element, order (k, e)
+    const bool live = i < KE;
+    const int per = (B + 3) / 4;
+    const int b_beg = wave * per, b_end = min(B, b_beg + per);
+    float acc = 0.f, bsum = 0.f;
+    for (int bb = b_beg; bb < b_end; bb += 64) {
+        int my_t0 = 0;
+        float my_g = 0.f;
+        if (bb + lane < b_end) {
+            const long fi = (long)(bb + lane) * w.F + w.col0[wi] + co;
+            const int t0 = arg[fi];
+            if (t0 >= 0 && t0 + Kw <= L) {
+                my_t0 = t0;
+                my_g = pooled_grad(w, dfeat, feat, fi);
+            }
+        }
+        const int nb = min(64, b_end - bb);
+        for (int c = 0; c < nb; ++c) {
+            const int t0 = __builtin_amdgcn_readlane(my_t0, c);
+            const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_g), c));
+            bsum += g;
+            if (live) acc += g * x[(long)(bb + c) * sent_stride + (long)t0 * E + i];  // g == 0 for closed gates
+        }
+    }
+    red[wave][lane] = acc;
+    if (lane == 0) redb[wave] = bsum;
+    __syncthreads();
+    if (wave == 0) {
+        const float tot = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        if (live) {
+            const int di = (w.layout == 0) ? i : (i % E) * Kw + (i / E);
+            float* d = w.dW[wi] + (long)co * KE + di;
+            *d = (beta != 0.f) ? tot + beta * (*d) : tot;
+        }
+        if (blockIdx.x == 0 && lane == 0 && w.db[wi]) {
+            const float bs = redb[0] + redb[1] + redb[2] + redb[3];
+            float* d = w.db[wi] + co;
+            *d = (beta != 0.f) ? bs + beta * (*d) : bs;
+        }
+    }
+}
+
+// Embedding-table gradient without atomics: dtable[v, :] (+)= sum over positions with idx == v of dx[pos, :].
+// One workgroup per table row; 16 position groups x 16 column lanes, fixed-order LDS reduction.
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ idx, const float* __restrict__ dx,
+                                                            int n, int E, float beta, float* __restrict__ dtable) {
+    __shared__ float red[16][17];
+    const int v = blockIdx.x;
+    const int pg = threadIdx.x >> 4, el = threadIdx.x & 15;
+    for (int e0 = 0; e0 < E; e0 += 16) {
+        const int e = e0 + el;
+        float s = 0.f;
+        if (e < E) {
+            for (int pos = pg; pos < n; pos += 16)
+                if (idx[pos] == (int64_t)v) s += dx[(long)pos * E + e];
+        }
+        __syncthreads();
+        red[pg][el] = s;
+        __syncthreads();
+        if (pg == 0 && e < E) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k][el];
+            float* d = dtable + (long)v * E + e;
+            *d = (beta != 0.f) ? t + beta * (*d) : t;
+        }
+    }
+}
+
+int fill_widths(ConvWidths& cw, const cgn_conv_widths* d, bool need_w, bool need_dw) {
+    if (!d || d->n < 1 || d->n > MAXW) return CGN_ERR_INVALID_ARG;
+    if (d->act != ACT_RELU && d->act != ACT_TANH) return CGN_ERR_INVALID_ARG;
+    if (d->layout != 0 && d->layout != 1) return CGN_ERR_INVALID_ARG;
+    cw.n = d->n; cw.F = d->F; cw.act = d->act; cw.layout = d->layout;
+    for (int i = 0; i < MAXW; ++i) {
+        cw.W[i] = nullptr; cw.dW[i] = nullptr; cw.db[i] = nullptr;
+        cw.K[i] = 0; cw.Co[i] = 0; cw.col0[i] = 0;
+    }
+    for (int i = 0; i < d->n; ++i) {
+        if (d->K[i] < 1 || d->Co[i] < 1 || d->col0[i] < 0 || d->col0[i] + d->Co[i] > d->F) return CGN_ERR_INVALID_ARG;
+        if (need_w && !d->W[i]) return CGN_ERR_INVALID_ARG;
+        if (need_dw && !d->dW[i]) return CGN_ERR_INVALID_ARG;
+        cw.K[i] = d->K[i]; cw.Co[i] = d->Co[i]; cw.col0[i] = d->col0[i];
+        cw.W[i] = d->W[i]; cw.dW[i] = d->dW[i]; cw.db[i] = d->db[i];
+    }
+    return CGN_OK;
+}
+
+}  // namespace
+
+extern "C" int cgn_act_maxpool_f32(void* stream, const float* conv, int32_t B, int32_t P, int32_t Co, int32_t act,
+                                   float* feat, int64_t ldf, int32_t col0, int32_t* arg, int64_t lda) {
+    CGN_CHECK_ARG(B >= 0 && P >= 1 && Co >= 1 && col0 >= 0 && (act == ACT_RELU || act == ACT_TANH));
+    if (B == 0) return CGN_OK;
+    CGN_CHECK_ARG(conv && feat && arg && ldf >= col0 + Co && lda >= col0 + Co);
+    int blocks = cgn_cdiv((long)B * Co, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(act_maxpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, conv, B, P, Co, act, feat,
+                       (long)ldf, col0, arg, (long)lda);
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}
+
+extern "C" int cgn_conv_bwd_dx_f32(void* stream, const cgn_conv_widths* widths, const float* dfeat, const float* feat,
+                                   const int32_t* arg, int32_t B, int32_t L, int32_t E, float* dx, int64_t sent_stride) {
+    CGN_CHECK_ARG(B >= 0 && L >= 1 && E >= 1);
+    if (B == 0) return CGN_OK;
+    ConvWidths cw;
+    int rc = fill_widths(cw, widths, true, false);
+    if (rc) return rc;
+    CGN_CHECK_ARG(dfeat && arg && dx && sent_stride >= (int64_t)L * E && (cw.act == ACT_RELU || feat));
+    CGN_CHECK_ARG(B <= 65535);
+    dim3 grid(cgn_cdiv((long)L * E, 256), B);
+    hipLaunchKernelGGL(conv_bwd_dx_kernel, grid, dim3(256), 0, (hipStream_t)stream, cw, dfeat, feat, arg, L, E, dx,
+                       (long)sent_stride);
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}
+
+extern "C" int cgn_conv_bwd_dw_f32(void* stream, const cgn_conv_widths* widths, const float* dfeat, const float* feat,
+                                   const int32_t* arg, const float* x, int64_t sent_stride, int32_t B, int32_t L,
+                                   int32_t E, float beta) {
+    CGN_CHECK_ARG(B >= 0 && L >= 1 && E >= 1);
+    ConvWidths cw;
+    int rc = fill_widths(cw, widths, false, true);
+    if (rc) return rc;
+    CGN_CHECK_ARG(dfeat && arg && x && sent_stride >= (int64_t)L * E && (cw.act == ACT_RELU || feat));
+    int maxco = 0, maxke = 0;
+    for (int i = 0; i < cw.n; ++i) {
+        if (cw.Co[i] > maxco) maxco = cw.Co[i];
+        if (cw.K[i] * E > maxke) maxke = cw.K[i] * E;
+    }
+    CGN_CHECK_ARG(maxco <= 65535);
+    dim3 grid(cgn_cdiv(maxke, 64), maxco, cw.n);
+    hipLaunchKernelGGL(conv_bwd_dw_kernel, grid, dim3(256), 0, (hipStream_t)stream, cw, dfeat, feat, arg, x,
+                       (long)sent_stride, B, L, E, beta);
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}
+
+extern "C" int cgn_embedding_bwd_f32(void* stream, const int64_t* idx, const float* dx, int32_t n, int32_t V, int32_t E,
+                                     float beta, float* dtable) {
+    CGN_CHECK_ARG(n >= 0 && V >= 1 && E >= 1);
+    CGN_CHECK_ARG(idx && dx && dtable);
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, idx, dx, n, E, beta, dtable);
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}

@@ -1,0 +1,264 @@
+// LSTM recurrence for gfx950: forward and BPTT step kernels (replaces the cuDNN RNN behind nn.LSTM at
+// model/encoder.py:17-21,40 and model/generator.py:17-20,58 of the reference).
+//
+// The time-batched input projections (x · W_ihᵀ + b_ih + b_hh) are MFMA GEMMs done by cgn_gemm_f32 beforehand; what
+// remains per timestep is gates = xg[:, t] + h_{t-1} · W_hhᵀ and the cell update. Per step that is a
+// [B,H]x[H,4H] product (134 MFLOP at B=64, H=512): latency-bound, so it is decomposed for parallelism, not tile size:
+//   * one workgroup = 16 batch rows x 16 hidden units (all four gates of those units), grid = (H/16, B/16, nseq)
+//     -> 256 workgroups (one per CU) for the encoder's two directions at cfg2;
+//   * its 4 waves split K four ways, each running v_mfma_f32_16x16x4_f32 chains on 4 independent accumulators
+//     (i, f, g, o tiles), then sum through LDS; the i/f/g/o of one (row, unit) land in the same lane/register of the
+//     four tiles, so the gate nonlinearities and the cell update need no cross-lane traffic;
+//   * operands are read straight from L2 into registers as float4 along k: lane (r, q) feeds k = 16s + 4q + i to the
+//     i-th MFMA of chunk s (any permutation of k is legal as long as A and B agree), so every load is a 16-byte
+//     access of a 64-byte contiguous row segment;
+//   * independent sequences (the encoder's two directions) advance in the same launch (blockIdx.z).
+// One launch per timestep: on MI355X a dependent kernel boundary (~1.5 us) is cheaper than a grid-wide barrier
+// (~4-5 us, MI355X_MICROARCH price list), so the seam between timesteps is a launch, not an in-kernel barrier.
+//
+// Buffers (all batch-major, fp32):
+//   xg    [B, T, 4H]  input projections incl. both biases, gate order i,f,g,o (torch layout)
+//   hbuf  [B, T+1, H] hidden history; forward sequences keep the initial state in slot 0 and h_t in slot t+1,
+//                      reverse sequences keep the initial state in slot T and h_t in slot t
+//   cbuf  [B, T+1, H] same for the cell state
+//   gates [B, T, 4H]  activated gates, saved for the backward pass
+#include "common.h"
+
+namespace {
+
+constexpr int LSTM_MAX_SEQ = 4;
+
+struct FwdSeq {
+    const float* xg;
+    const float* xg_extra;
+    const float* w_hh;
+    float* hbuf;
+    float* cbuf;
+    float* gates;
+    int reverse;
+};
+struct FwdParams {
+    FwdSeq s[LSTM_MAX_SEQ];
+    int B, T, H, step;
+};
+
+struct BwdSeq {
+    const float* w_hh_t;
+    const float* cbuf;
+    const float* gates;
+    const float* dh_ext;
+    const float* dh_seed;
+    float* dgates;
+    float* dc_state;
+    long dh_bs, dh_ts;
+    int reverse;
+};
+struct BwdParams {
+    BwdSeq s[LSTM_MAX_SEQ];
+    int B, T, H, step;
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const FwdParams p) {
+    __shared__ float red[4][16][64];
+    const FwdSeq& sq = p.s[blockIdx.z];
+    const int B = p.B, T = p.T, H = p.H;
+    const int t = sq.reverse ? (T - 1 - p.step) : p.step;
+    const int slot_prev = sq.reverse ? t + 1 : t;
+    const int slot_out = sq.reverse ? t : t + 1;
+    const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, q = lane >> 4;
+
+    const int nchunks = (H + 15) / 16;
+    const int cpw = (nchunks + 3) / 4;
+    const int c_beg = wave * cpw, c_end = min(nchunks, c_beg + cpw);
+
+    const int bA = b0 + fr;  // A operand row
+    const int jB = j0 + fr;  // B operand column = hidden unit
+    const bool a_ok = bA < B, b_ok = jB < H;
+    const float* hrow = sq.hbuf + ((long)bA * (T + 1) + slot_prev) * H;
+    const float* wrow = sq.w_hh + (long)jB * H;
+    const long gate_stride = (long)H * H;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = {0.f, 0.f, 0.f, 0.f};
+
+    for (int c = c_beg; c < c_end; ++c) {
+        const int kb = c * 16 + q * 4;
+        const bool k_ok = kb < H;  // H % 4 == 0 (checked on the host), so kb < H implies kb + 3 < H
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (a_ok && k_ok) a = ld4(hrow + kb);
+        f32x4 w[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            w[g] = {0.f, 0.f, 0.f, 0.f};
+            if (b_ok && k_ok) w[g] = ld4(wrow + g * gate_stride + kb);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], w[g][i], acc[g], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][g * 4 + r][lane] = acc[g][r];
+    __syncthreads();
+
+    // thread (lane', r) finishes element (row = (lane'>>4)*4 + r, unit = lane'&15): C/D map of the 16x16 MFMA
+    const int r = wave;
+    const int b = b0 + (lane >> 4) * 4 + r;
+    const int j = j0 + (lane & 15);
+    if (b < B && j < H) {
+        float pre[4];
+        const float* xg = sq.xg + ((long)b * T + t) * 4 * H;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v = red[0][g * 4 + r][lane] + red[1][g * 4 + r][lane] + red[2][g * 4 + r][lane] +
+                      red[3][g * 4 + r][lane];
+            v += xg[g * H + j];
+            if (sq.xg_extra) v += sq.xg_extra[(long)b * 4 * H + g * H + j];
+            pre[g] = v;
+        }
+        const float ig = cgn_sigmoid(pre[0]);
+        const float fg = cgn_sigmoid(pre[1]);
+        const float gg = tanhf(pre[2]);
+        const float og = cgn_sigmoid(pre[3]);
+        const float cprev = sq.cbuf[((long)b * (T + 1) + slot_prev) * H + j];
+        const float cn = fg * cprev + ig * gg;
+        const float hn = og * tanhf(cn);
+        float* go = sq.gates + ((long)b * T + t) * 4 * H;
+        go[j] = ig;
+        go[H + j] = fg;
+        go[2 * H + j] = gg;
+        go[3 * H + j] = og;
+        sq.cbuf[((long)b * (T + 1) + slot_out) * H + j] = cn;
+        sq.hbuf[((long)b * (T + 1) + slot_out) * H + j] = hn;
+    }
+}
+
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const BwdParams p) {
+    __shared__ float red[4][4][64];
+    const BwdSeq& sq = p.s[blockIdx.z];
+    const int B = p.B, T = p.T, H = p.H;
+    // processing order is the reverse of the forward pass
+    const int t = sq.reverse ? p.step : (T - 1 - p.step);
+    const int t_next = sq.reverse ? t - 1 : t + 1;  // the timestep processed just before this one
+    const bool first = p.step == 0;
+    const int slot_prev = sq.reverse ? t + 1 : t;
+    const int slot_out = sq.reverse ? t : t + 1;
+    const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, q = lane >> 4;
+    const int K = 4 * H;
+
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if (!first) {
+        const int nchunks = K / 16;  // H % 4 == 0 => 4H % 16 == 0
+        const int cpw = (nchunks + 3) / 4;
+        const int c_beg = wave * cpw, c_end = min(nchunks, c_beg + cpw);
+        const int bA = b0 + fr, jB = j0 + fr;
+        const bool a_ok = bA < B, b_ok = jB < H;
+        const float* arow = sq.dgates + ((long)bA * T + t_next) * K;
+        const float* wrow = sq.w_hh_t + (long)jB * K;
+        int c = c_beg;
+        for (; c + 1 < c_end; c += 2) {
+            const int kb0 = c * 16 + q * 4, kb1 = kb0 + 16;
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, w0 = a0, w1 = a0;
+            if (a_ok) {
+                a0 = ld4(arow + kb0);
+                a1 = ld4(arow + kb1);
+            }
+            if (b_ok) {
+                w0 = ld4(wrow + kb0);
+                w1 = ld4(wrow + kb1);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], w0[i], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i], w1[i], acc1, 0, 0, 0);
+            }
+        }
+        if (c < c_end) {
+            const int kb0 = c * 16 + q * 4;
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, w0 = a0;
+            if (a_ok) a0 = ld4(arow + kb0);
+            if (b_ok) w0 = ld4(wrow + kb0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], w0[i], acc0, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc0[r] + acc1[r];
+    __syncthreads();
+
+    const int r = wave;
+    const int b = b0 + (lane >> 4) * 4 + r;
+    const int j = j0 + (lane & 15);
+    if (b < B && j < H) {
+        float dh = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
+        if (first && sq.dh_seed) dh += sq.dh_seed[(long)b * H + j];
+        if (sq.dh_ext) dh += sq.dh_ext[(long)b * sq.dh_bs + (long)t * sq.dh_ts + j];
+        const float* gt = sq.gates + ((long)b * T + t) * K;
+        const float ig = gt[j], fg = gt[H + j], gg = gt[2 * H + j], og = gt[3 * H + j];
+        const float cprev = sq.cbuf[((long)b * (T + 1) + slot_prev) * H + j];
+        const float tc = tanhf(sq.cbuf[((long)b * (T + 1) + slot_out) * H + j]);
+        const float dc = sq.dc_state[(long)b * H + j] + dh * og * (1.f - tc * tc);
+        float* dg = sq.dgates + ((long)b * T + t) * K;
+        dg[j] = dc * gg * ig * (1.f - ig);
+        dg[H + j] = dc * cprev * fg * (1.f - fg);
+        dg[2 * H + j] = dc * ig * (1.f - gg * gg);
+        dg[3 * H + j] = dh * tc * og * (1.f - og);
+        sq.dc_state[(long)b * H + j] = dc * fg;
+    }
+}
+
+}  // namespace
+
+extern "C" int cgn_lstm_seq_fwd_f32(void* stream, const cgn_lstm_fwd_seq* seqs, int32_t nseq, int32_t B, int32_t T,
+                                    int32_t H) {
+    CGN_CHECK_ARG(seqs && nseq >= 1 && nseq <= LSTM_MAX_SEQ);
+    CGN_CHECK_ARG(B >= 0 && T >= 0 && H > 0 && H % 4 == 0);
+    if (B == 0 || T == 0) return CGN_OK;
+    FwdParams p;
+    for (int i = 0; i < nseq; ++i) {
+        const cgn_lstm_fwd_seq& s = seqs[i];
+        CGN_CHECK_ARG(s.xg && s.w_hh && s.hbuf && s.cbuf && s.gates);
+        CGN_CHECK_ARG(((uintptr_t)s.hbuf % 16 == 0) && ((uintptr_t)s.w_hh % 16 == 0));
+        p.s[i] = {s.xg, s.xg_extra, s.w_hh, s.hbuf, s.cbuf, s.gates, s.reverse};
+    }
+    p.B = B; p.T = T; p.H = H;
+    dim3 grid(cgn_cdiv(H, 16), cgn_cdiv(B, 16), nseq);
+    for (int step = 0; step < T; ++step) {
+        p.step = step;
+        hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    }
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}
+
+extern "C" int cgn_lstm_seq_bwd_f32(void* stream, const cgn_lstm_bwd_seq* seqs, int32_t nseq, int32_t B, int32_t T,
+                                    int32_t H) {
+    CGN_CHECK_ARG(seqs && nseq >= 1 && nseq <= LSTM_MAX_SEQ);
+    CGN_CHECK_ARG(B >= 0 && T >= 0 && H > 0 && H % 4 == 0);
+    if (B == 0 || T == 0) return CGN_OK;
+    BwdParams p;
+    for (int i = 0; i < nseq; ++i) {
+        const cgn_lstm_bwd_seq& s = seqs[i];
+        CGN_CHECK_ARG(s.w_hh_t && s.cbuf && s.gates && s.dgates && s.dc_state);
+        CGN_CHECK_ARG(((uintptr_t)s.dgates % 16 == 0) && ((uintptr_t)s.w_hh_t % 16 == 0));
+        p.s[i] = {s.w_hh_t, s.cbuf, s.gates, s.dh_ext, s.dh_seed, s.dgates, s.dc_state, s.dh_bs, s.dh_ts, s.reverse};
+    }
+    p.B = B; p.T = T; p.H = H;
+    dim3 grid(cgn_cdiv(H, 16), cgn_cdiv(B, 16), nseq);
+    for (int step = 0; step < T; ++step) {
+        p.step = step;
+        hipLaunchKernelGGL(lstm_step_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    }
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}

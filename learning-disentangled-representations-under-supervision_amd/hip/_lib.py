@@ -46,11 +46,56 @@ class GemmDesc(C.Structure):
     ]
 
 
+class LstmFwdSeq(C.Structure):
+    _fields_ = [("xg", c_ptr), ("xg_extra", c_ptr), ("w_hh", c_ptr), ("hbuf", c_ptr), ("cbuf", c_ptr),
+                ("gates", c_ptr), ("reverse", c_i32)]
+
+
+class LstmBwdSeq(C.Structure):
+    _fields_ = [("w_hh_t", c_ptr), ("cbuf", c_ptr), ("gates", c_ptr), ("dh_ext", c_ptr), ("dh_seed", c_ptr),
+                ("dgates", c_ptr), ("dc_state", c_ptr), ("dh_bs", c_i64), ("dh_ts", c_i64), ("reverse", c_i32)]
+
+
+class ConvWidths(C.Structure):
+    _fields_ = [("W", c_ptr * 8), ("dW", c_ptr * 8), ("db", c_ptr * 8),
+                ("K", c_i32 * 8), ("Co", c_i32 * 8), ("col0", c_i32 * 8),
+                ("n", c_i32), ("F", c_i32), ("act", c_i32), ("layout", c_i32)]
+
+
+ACT_RELU = 0
+ACT_TANH = 1
+
 # name -> (restype, argtypes); mirrors include/cgn_hip.h one to one (tests check the header against this table)
 PROTOTYPES = {
     "cgn_abi_version": (c_i32, []),
     "cgn_gemm_f32": (c_i32, [c_ptr, C.POINTER(GemmDesc)]),
     "cgn_softmax_nll_fwd_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_i32, c_f32, c_ptr, c_ptr, c_ptr]),
+    "cgn_lstm_seq_fwd_f32": (c_i32, [c_ptr, C.POINTER(LstmFwdSeq), c_i32, c_i32, c_i32, c_i32]),
+    "cgn_lstm_seq_bwd_f32": (c_i32, [c_ptr, C.POINTER(LstmBwdSeq), c_i32, c_i32, c_i32, c_i32]),
+    "cgn_act_maxpool_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr, c_i64, c_i32, c_ptr, c_i64]),
+    "cgn_conv_bwd_dx_f32": (c_i32, [c_ptr, C.POINTER(ConvWidths), c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr,
+                                    c_i64]),
+    "cgn_conv_bwd_dw_f32": (c_i32, [c_ptr, C.POINTER(ConvWidths), c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32,
+                                    c_i32, c_f32]),
+    "cgn_embedding_bwd_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_f32, c_ptr]),
+    "cgn_copy2d_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_f32, c_f32]),
+    "cgn_transpose_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_ptr]),
+    "cgn_gather_rows_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i64]),
+    "cgn_highway_gate_fwd_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i64]),
+    "cgn_highway_gate_bwd_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
+    "cgn_reparam_kld_fwd_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr]),
+    "cgn_reparam_kld_bwd_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_i32, c_i32, c_ptr]),
+    "cgn_colsum_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_i32, c_f32, c_ptr, c_ptr, c_i64]),
+    "cgn_sum_time_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr]),
+    "cgn_rowdot_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_ptr]),
+    "cgn_adam_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32]),
+    "cgn_disc_head_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_f32, c_f32, c_ptr,
+                                  c_ptr, c_ptr, c_ptr]),
+    "cgn_disc_head_bwd_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_f32, c_ptr, c_ptr,
+                                      c_ptr]),
+    "cgn_bernoulli_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_i32, c_ptr]),
+    "cgn_fill_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_f32]),
+    "cgn_lincomb_f32": (c_i32, [c_ptr, c_i32, C.POINTER(c_ptr), C.POINTER(c_f32), c_ptr]),
 }
 
 _lib = None

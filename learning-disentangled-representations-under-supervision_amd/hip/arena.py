@@ -1,0 +1,52 @@
+"""Flat fp32 parameter arenas: one contiguous buffer per optimizer group for params, grads and Adam moments.
+
+Why: (1) Adam for a whole group is ONE streaming kernel (cgn_adam_f32) instead of a launch per tensor; (2) the
+data-parallel gradient all-reduce is a handful of large contiguous buckets per group (RCCL over xGMI is per-link
+bound, so few large messages beat many small ones); (3) `zero_grad` is one fill. Module parameters become views into
+the arena (same names/shapes, so state_dict round-trips with the reference's checkpoints).
+"""
+import torch
+
+from . import ops
+
+ALIGN = 64  # floats (256 B): keeps every tensor 16-byte aligned for float4 access
+
+
+class ParamArena:
+    def __init__(self, named_params, device):
+        """named_params: list of (name, nn.Parameter). Parameters are re-pointed at views of the arena."""
+        self.names = [n for n, _ in named_params]
+        self.offsets, off = {}, 0
+        for n, p in named_params:
+            self.offsets[n] = (off, p.numel(), tuple(p.shape))
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.size = off
+        self.p = torch.zeros(off, dtype=torch.float32, device=device)
+        self.g = torch.zeros(off, dtype=torch.float32, device=device)
+        self.m = torch.zeros(off, dtype=torch.float32, device=device)
+        self.v = torch.zeros(off, dtype=torch.float32, device=device)
+        self.step = 0
+        self.params, self.grads = {}, {}
+        for n, p in named_params:
+            o, ne, shape = self.offsets[n]
+            view = self.p[o:o + ne].view(shape)
+            view.copy_(p.data)
+            p.data = view
+            gview = self.g[o:o + ne].view(shape)
+            p.grad = gview
+            self.params[n] = p
+            self.grads[n] = gview
+
+    def owns(self, named_params):
+        """True while every parameter still aliases this arena (a .cuda()/.to() on the module breaks that)."""
+        base = self.p.untyped_storage().data_ptr()
+        return all(p.data.untyped_storage().data_ptr() == base for _, p in named_params)
+
+    def zero_grad(self):
+        if self.size:
+            ops.fill(self.g, 0.0)
+
+    def adam_step(self, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
+        self.step += 1
+        if self.size:
+            ops.adam(self.p, self.g, self.m, self.v, lr, self.step, betas[0], betas[1], eps, grad_scale)

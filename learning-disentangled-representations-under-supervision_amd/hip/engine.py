@@ -1,0 +1,227 @@
+"""Forward/backward building blocks of the CGN step, composed from the C-ABI kernels (hip/ops.py).
+
+Every block is a pair  fwd(...) -> (outputs, saved)  /  bwd(saved, upstream grads, grad buffers) and calls only
+hand-written HIP kernels; torch supplies device buffers. Parameter gradients are WRITTEN (beta=0) or ACCUMULATED
+(beta=1) into caller-provided tensors (views of the flat gradient arenas, hip/arena.py), which is what lets the
+training step reproduce the reference's backward order and optimizer grouping without autograd.
+
+Layouts are batch-major like the reference API ([B,L,Din] inputs, [B,T,V] logits); LSTM histories are [B,T+1,H]
+buffers addressed in place by the GEMMs (two-level axes), never copied.
+"""
+import torch
+
+from . import ops
+from ._lib import ACT_RELU, ACT_TANH, Axis
+
+
+def _new(shape, dev, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
+LIN = Axis(1, 0, 0)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# linear
+# ------------------------------------------------------------------------------------------------------------------
+def linear_fwd(x2d, W, b, out):
+    """out = x2d @ W^T + b   (nn.Linear)."""
+    return ops.gemm(x2d, W.t(), out, bias0=b)
+
+
+def linear_bwd(x2d, W, dy, dW, db, dx=None, beta=0.0, dx_beta=0.0):
+    ops.gemm(dy.t(), x2d, dW, beta=beta)
+    if db is not None:
+        ops.colsum(dy, db, beta=beta)
+    if dx is not None:
+        ops.gemm(dy, W, dx, beta=dx_beta)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# char-TDNN (selfModules/tdnn.py:18-48) incl. the char-embedding lookup (selfModules/embedding.py:44-51)
+# ------------------------------------------------------------------------------------------------------------------
+def tdnn_fwd(char_idx, char_table, kernels):
+    """char_idx [N, W] int64 -> feat [N, S] (contiguous). kernels: list of [od, Cc, kW]."""
+    N, Wl = char_idx.shape
+    CV, Cc = char_table.shape
+    dev = char_table.device
+    xw = _new((N * Wl, Cc), dev)
+    ops.gather_rows(char_table, char_idx.reshape(-1), xw)
+    S = sum(k.shape[0] for k in kernels)
+    feat = _new((N, S), dev)
+    arg = _new((N, S), dev, torch.int32)
+    col = 0
+    for k in kernels:
+        od, _, kW = k.shape
+        if kW > Wl:
+            raise RuntimeError("TDNN kernel width %d exceeds max_word_len %d" % (kW, Wl))
+        P = Wl - kW + 1
+        conv = _new((N * P, od), dev)
+        # row (n,p) = xw[n, p:p+kW, :] (contiguous kW*Cc floats, order (j,c)); weight element (o, c, j) -> k = j*Cc + c
+        ops.gemm(xw, k, conv, M=N * P, N=od, K=kW * Cc,
+                 a_m=Axis(Cc, P, Wl * Cc), a_k=LIN,
+                 b_k=Axis(kW, Cc, 1), b_n=Axis(Cc * kW, 0, 0))
+        ops.act_maxpool(conv, N, P, ACT_TANH, feat, col, arg)
+        col += od
+    return feat, dict(xw=xw, feat=feat, arg=arg, char_idx=char_idx, N=N, W=Wl, Cc=Cc)
+
+
+def tdnn_bwd(saved, kernels, dfeat, dkernels, dchar_table, beta=0.0):
+    """dfeat [N,S] contiguous -> kernel grads and the char-embedding table gradient."""
+    N, Wl, Cc = saved["N"], saved["W"], saved["Cc"]
+    Ks = [k.shape[2] for k in kernels]
+    Cos = [k.shape[0] for k in kernels]
+    ops.conv_bwd_dw(Ks, Cos, ACT_TANH, 1, dkernels, None, dfeat, saved["feat"], saved["arg"], saved["xw"], Wl * Cc, N,
+                    Wl, Cc, beta=beta)
+    dxw = _new((N * Wl, Cc), dfeat.device)
+    ops.conv_bwd_dx(Ks, Cos, ACT_TANH, 1, list(kernels), dfeat, saved["feat"], saved["arg"], N, Wl, Cc, dxw, Wl * Cc)
+    ops.embedding_bwd(saved["char_idx"].reshape(-1), dxw, dchar_table, beta=beta)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# highway (selfModules/highway.py:27-46), f = relu as used by the encoder (model/encoder.py:15)
+# ------------------------------------------------------------------------------------------------------------------
+def highway_fwd(x, layers):
+    """x [N,S]; layers: list of dict(nw, nb, lw, lb, gw, gb). Returns y and the per-layer saved (input, pre)."""
+    N, S = x.shape
+    saved = []
+    for p in layers:
+        pre = _new((N, 3 * S), x.device)
+        ops.gemm(x, p["nw"].t(), pre[:, 0:S], bias0=p["nb"])
+        ops.gemm(x, p["lw"].t(), pre[:, S:2 * S], bias0=p["lb"])
+        ops.gemm(x, p["gw"].t(), pre[:, 2 * S:3 * S], bias0=p["gb"])
+        y = _new((N, S), x.device)
+        ops.highway_gate_fwd(pre, y)
+        saved.append((x, pre))
+        x = y
+    return x, saved
+
+
+def highway_bwd(saved, layers, dy, grads, need_dx, beta=0.0):
+    """grads: list of dict(nw, nb, lw, lb, gw, gb) gradient tensors (may be None to skip parameter grads)."""
+    dx = None
+    for li in range(len(layers) - 1, -1, -1):
+        x, pre = saved[li]
+        p = layers[li]
+        N, S = x.shape
+        dpre = _new((N, 3 * S), x.device)
+        ops.highway_gate_bwd(pre, dy, dpre)
+        views = (dpre[:, 0:S], dpre[:, S:2 * S], dpre[:, 2 * S:3 * S])
+        if grads is not None:
+            g = grads[li]
+            for v, wn, bn in zip(views, ("nw", "lw", "gw"), ("nb", "lb", "gb")):
+                ops.gemm(v.t(), x, g[wn], beta=beta)
+                ops.colsum(v, g[bn], beta=beta)
+        if li > 0 or need_dx:
+            dx = _new((N, S), x.device)
+            ops.gemm(views[0], p["nw"], dx)
+            ops.gemm(views[1], p["lw"], dx, beta=1.0)
+            ops.gemm(views[2], p["gw"], dx, beta=1.0)
+            dy = dx
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# LSTM (nn.LSTM, batch_first, zero or given initial state)
+# ------------------------------------------------------------------------------------------------------------------
+class LstmSeq:
+    """One direction of one layer: buffers + addressing helpers."""
+
+    def __init__(self, B, T, H, dev, reverse):
+        self.B, self.T, self.H, self.reverse = B, T, H, reverse
+        self.xg = _new((B, T, 4 * H), dev)
+        self.hbuf = _new((B, T + 1, H), dev)
+        self.cbuf = _new((B, T + 1, H), dev)
+        self.gates = _new((B, T, 4 * H), dev)
+        self.xg_extra = None
+        self.init_slot = T if reverse else 0
+        self.final_slot = 0 if reverse else T
+
+    def set_initial(self, h0=None, c0=None):
+        for buf, init in ((self.hbuf, h0), (self.cbuf, c0)):
+            slot = buf[:, self.init_slot, :]
+            if init is None:
+                ops.copy2d(slot, slot, scale=0.0)  # zero the slot with a kernel (no torch arithmetic on the path)
+            else:
+                ops.copy2d(init, slot)
+
+    # emitted h as a GEMM operand with rows (b,t): element (m, k) = hbuf[b, t + off, k]
+    def hout_operand(self):
+        off = 0 if self.reverse else 1
+        base = self.hbuf.view(-1)[off * self.H:]
+        return base, Axis(self.H, self.T, (self.T + 1) * self.H)
+
+    def hprev_operand(self):
+        off = 1 if self.reverse else 0
+        base = self.hbuf.view(-1)[off * self.H:]
+        return base, Axis(self.H, self.T, (self.T + 1) * self.H)
+
+    def h_final(self):
+        return self.hbuf[:, self.final_slot, :]
+
+    def c_final(self):
+        return self.cbuf[:, self.final_slot, :]
+
+    def fwd_desc(self, w_hh):
+        return dict(xg=self.xg, xg_extra=self.xg_extra, w_hh=w_hh, hbuf=self.hbuf, cbuf=self.cbuf, gates=self.gates,
+                    reverse=self.reverse)
+
+
+def lstm_run_fwd(seqs, w_hhs):
+    s0 = seqs[0]
+    ops.lstm_seq_fwd([s.fwd_desc(w) for s, w in zip(seqs, w_hhs)], s0.B, s0.T, s0.H)
+
+
+def lstm_run_bwd(seqs, w_hhs, dh_exts, dh_seeds, dc_states):
+    """Returns dgates per sequence. dh_exts: list of None | (tensor, batch_stride, time_stride)."""
+    s0 = seqs[0]
+    dev = s0.xg.device
+    descs, outs = [], []
+    for s, w, ext, seed, dc in zip(seqs, w_hhs, dh_exts, dh_seeds, dc_states):
+        wt = _new((s.H, 4 * s.H), dev)
+        ops.transpose(w, wt)
+        dg = _new((s.B, s.T, 4 * s.H), dev)
+        d = dict(w_hh_t=wt, cbuf=s.cbuf, gates=s.gates, dgates=dg, dc_state=dc, dh_seed=seed, reverse=s.reverse)
+        if ext is not None:
+            d["dh_ext"], d["dh_bs"], d["dh_ts"] = ext
+        descs.append(d)
+        outs.append(dg)
+    ops.lstm_seq_bwd(descs, s0.B, s0.T, s0.H)
+    return outs
+
+
+def lstm_param_grads(seq, dgates, x_operand, dW_ih, dW_hh, db_ih, db_hh, beta=0.0):
+    """x_operand: (tensor, k_axis) describing x rows (b,t) as the B operand [K=B*T, Din] of dW_ih = dG^T x."""
+    B, T, H = seq.B, seq.T, seq.H
+    dg2 = dgates.view(B * T, 4 * H)
+    xt, xk = x_operand
+    if dW_ih is not None:
+        ops.gemm(dg2.t(), xt, dW_ih, N=dW_ih.shape[1], K=B * T, b_k=xk, b_n=LIN, beta=beta)
+    hp, hk = seq.hprev_operand()
+    ops.gemm(dg2.t(), hp, dW_hh, N=H, K=B * T, b_k=hk, b_n=LIN, beta=beta)
+    ops.colsum(dg2, db_ih, beta=beta)
+    ops.colsum(dg2, db_hh, beta=beta)
+    return dg2
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# text-CNN discriminator (model/discriminator_sentiment.py:56-78)
+# ------------------------------------------------------------------------------------------------------------------
+def textcnn_features_fwd(x, B, L, E, sent_stride, conv_w, conv_b):
+    """x: tensor whose element (b,t,e) sits at b*sent_stride + t*E + e. Returns feat [B,F], arg [B,F]."""
+    dev = x.device
+    Cos = [w.shape[0] for w in conv_w]
+    F = sum(Cos)
+    feat = _new((B, F), dev)
+    arg = _new((B, F), dev, torch.int32)
+    col = 0
+    for w, b in zip(conv_w, conv_b):
+        Co, _, K, Ew = w.shape
+        if K > L:
+            raise RuntimeError("Kernel size can't be greater than actual input size (K=%d, L=%d)" % (K, L))
+        P = L - K + 1
+        conv = _new((B * P, Co), dev)
+        ops.gemm(x, w.view(Co, K * E).t(), conv, M=B * P, K=K * E, a_m=Axis(E, P, sent_stride), a_k=LIN, bias0=b)
+        ops.act_maxpool(conv, B, P, ACT_RELU, feat, col, arg)
+        col += Co
+    return feat, arg

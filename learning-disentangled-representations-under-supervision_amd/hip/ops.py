@@ -163,3 +163,319 @@ def softmax_nll_fwd(logits, target, inv_tau):
         _lib.check(lib.cgn_softmax_nll_fwd_f32(_stream(), _ptr(logits), logits.stride(0), _ptr(target), M, V,
                                                inv_tau, _ptr(lse), _ptr(nll), _ptr(loss)), "cgn_softmax_nll_fwd_f32")
     return lse, nll, loss
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# thin wrappers over the remaining entry points; each checks shapes on the host before launching
+# ------------------------------------------------------------------------------------------------------------------
+def _call(name, dev, *args):
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        _lib.check(getattr(lib, name)(_stream(), *args), name)
+
+
+def _req(cond, msg):
+    if not cond:
+        raise ValueError(msg)
+
+
+def _rows2d(t, name):
+    """[R, C] view with unit column stride; returns (tensor, ld)."""
+    _chk_f32(t, name)
+    _req(t.dim() == 2 and (t.stride(1) == 1 or t.shape[1] == 1), "%s must be 2-D with unit column stride" % name)
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def fill(t, v):
+    _chk_f32(t, "t")
+    _req(t.is_contiguous(), "fill needs a contiguous tensor")
+    _call("cgn_fill_f32", t.device, _ptr(t), t.numel(), float(v))
+    return t
+
+
+def copy2d(src, dst, scale=1.0, beta=0.0):
+    lds, ldd = _rows2d(src, "src"), _rows2d(dst, "dst")
+    _req(src.shape == dst.shape, "copy2d shape mismatch")
+    _call("cgn_copy2d_f32", dst.device, _ptr(src), lds, _ptr(dst), ldd, src.shape[0], src.shape[1], scale, beta)
+    return dst
+
+
+def transpose(src, dst):
+    _chk_f32(src, "src"), _chk_f32(dst, "dst")
+    _req(src.dim() == 2 and src.is_contiguous() and dst.is_contiguous() and dst.shape == (src.shape[1], src.shape[0]),
+         "transpose needs contiguous [R,C] -> [C,R]")
+    _call("cgn_transpose_f32", dst.device, _ptr(src), src.shape[0], src.shape[1], _ptr(dst))
+    return dst
+
+
+def gather_rows(table, idx, out, mask=None):
+    """out[i,:] = table[idx[i],:] (* mask[i,:]). out is [n, E] (row stride free)."""
+    _chk_f32(table, "table"), _chk_i64(idx, "idx")
+    ldo = _rows2d(out, "out")
+    V, E = table.shape
+    n = idx.numel()
+    _req(table.is_contiguous() and out.shape == (n, E), "gather_rows shapes")
+    if mask is not None:
+        _chk_f32(mask, "mask")
+        _req(mask.is_contiguous() and mask.numel() == n * E, "mask must be [n,E]")
+    _call("cgn_gather_rows_f32", out.device, _ptr(table), V, E, _ptr(idx), n, _ptr(mask), _ptr(out), ldo)
+    return out
+
+
+def highway_gate_fwd(pre, out):
+    _chk_f32(pre, "pre")
+    N, S3 = pre.shape
+    S = S3 // 3
+    ldo = _rows2d(out, "out")
+    _req(pre.is_contiguous() and S3 == 3 * S and out.shape == (N, S), "highway_gate_fwd shapes")
+    _call("cgn_highway_gate_fwd_f32", out.device, _ptr(pre), N, S, _ptr(out), ldo)
+    return out
+
+
+def highway_gate_bwd(pre, dy, dpre):
+    _chk_f32(pre, "pre"), _chk_f32(dpre, "dpre")
+    N, S3 = pre.shape
+    S = S3 // 3
+    ldy = _rows2d(dy, "dy")
+    _req(pre.is_contiguous() and dpre.is_contiguous() and dpre.shape == pre.shape and dy.shape == (N, S),
+         "highway_gate_bwd shapes")
+    _call("cgn_highway_gate_bwd_f32", dpre.device, _ptr(pre), N, S, _ptr(dy), ldy, _ptr(dpre))
+    return dpre
+
+
+def reparam_kld_fwd(mulv, eps, c, zc, stdv, kld):
+    B, Z2 = mulv.shape
+    Z = Z2 // 2
+    Cc = zc.shape[1] - Z
+    for t, n in ((mulv, "mulv"), (eps, "eps"), (zc, "zc"), (stdv, "stdv"), (kld, "kld")):
+        _chk_f32(t, n)
+        _req(t.is_contiguous(), n + " must be contiguous")
+    _req(eps.shape == (B, Z) and stdv.shape == (B, Z) and zc.shape[0] == B and Cc >= 0 and kld.numel() == 1,
+         "reparam_kld_fwd shapes")
+    if Cc > 0:
+        _chk_f32(c, "c")
+        _req(c.is_contiguous() and c.numel() == B * Cc, "c must be [B,C]")
+    _call("cgn_reparam_kld_fwd_f32", zc.device, _ptr(mulv), _ptr(eps), _ptr(c if Cc > 0 else None), B, Z, Cc, _ptr(zc),
+          _ptr(stdv), _ptr(kld))
+
+
+def reparam_kld_bwd(mulv, eps, g, kld_weight, dmulv):
+    B, Z2 = mulv.shape
+    Z = Z2 // 2
+    for t, n in ((mulv, "mulv"), (eps, "eps"), (dmulv, "dmulv")):
+        _chk_f32(t, n)
+        _req(t.is_contiguous(), n + " must be contiguous")
+    _req(eps.shape == (B, Z) and dmulv.shape == mulv.shape, "reparam_kld_bwd shapes")
+    ldg = 0
+    if g is not None:
+        ldg = _rows2d(g, "g")
+        _req(g.shape[0] == B and g.shape[1] >= Z, "g must be [B, >=Z]")
+    _call("cgn_reparam_kld_bwd_f32", dmulv.device, _ptr(mulv), _ptr(eps), _ptr(g), ldg, kld_weight, B, Z, _ptr(dmulv))
+    return dmulv
+
+
+def colsum(x, out, beta=0.0):
+    ld = _rows2d(x, "x")
+    _chk_f32(out, "out")
+    R, Cn = x.shape
+    _req(out.is_contiguous() and out.numel() == Cn, "colsum out must have C elements")
+    ws = workspace(x.device)
+    _call("cgn_colsum_f32", x.device, _ptr(x), ld, R, Cn, beta, _ptr(out), _ptr(ws), ws.numel() * 4)
+    return out
+
+
+def sum_time(x, out):
+    _chk_f32(x, "x"), _chk_f32(out, "out")
+    B, T, Cn = x.shape
+    _req(x.is_contiguous() and out.is_contiguous() and out.shape == (B, Cn), "sum_time shapes")
+    _call("cgn_sum_time_f32", x.device, _ptr(x), B, T, Cn, _ptr(out))
+    return out
+
+
+def rowdot(a, b, out):
+    lda, ldb = _rows2d(a, "a"), _rows2d(b, "b")
+    _chk_f32(out, "out")
+    _req(a.shape == b.shape and out.is_contiguous() and out.numel() == a.shape[0], "rowdot shapes")
+    _call("cgn_rowdot_f32", a.device, _ptr(a), lda, _ptr(b), ldb, a.shape[0], a.shape[1], _ptr(out))
+    return out
+
+
+def adam(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    n = p.numel()
+    for t, nme in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk_f32(t, nme)
+        _req(t.is_contiguous() and t.numel() == n, "adam arenas must be contiguous and equally sized")
+    _call("cgn_adam_f32", p.device, _ptr(p), _ptr(g), _ptr(m), _ptr(v), n, lr, beta1, beta2, eps, int(step),
+          grad_scale)
+
+
+def disc_head(feat, W, bias, logits, *, mask=None, y=None, w_ce=0.0, w_ent=0.0, p1=None, dlogits=None, stats=None):
+    ldf = _rows2d(feat, "feat")
+    B, F = feat.shape
+    _chk_f32(W, "W"), _chk_f32(bias, "bias"), _chk_f32(logits, "logits")
+    _req(W.is_contiguous() and W.shape == (2, F) and bias.numel() == 2 and logits.is_contiguous()
+         and logits.shape == (B, 2), "disc_head shapes")
+    if mask is not None:
+        _chk_f32(mask, "mask")
+        _req(mask.is_contiguous() and mask.shape == (B, F), "mask must be [B,F]")
+    if y is not None:
+        _chk_i64(y, "y")
+        _req(y.numel() == B, "y must have B elements")
+    for t, n, ne in ((p1, "p1", B), (dlogits, "dlogits", 2 * B), (stats, "stats", 2)):
+        if t is not None:
+            _chk_f32(t, n)
+            _req(t.is_contiguous() and t.numel() == ne, n + " size")
+    _call("cgn_disc_head_f32", feat.device, _ptr(feat), ldf, _ptr(mask), _ptr(W), _ptr(bias), _ptr(y), B, F, w_ce, w_ent,
+          _ptr(logits), _ptr(p1), _ptr(dlogits), _ptr(stats))
+
+
+def disc_head_bwd(feat, W, dlogits, *, mask=None, beta=0.0, dW=None, db=None, dfeat=None):
+    ldf = _rows2d(feat, "feat")
+    B, F = feat.shape
+    _chk_f32(W, "W"), _chk_f32(dlogits, "dlogits")
+    _req(W.is_contiguous() and W.shape == (2, F) and dlogits.is_contiguous() and dlogits.numel() == 2 * B,
+         "disc_head_bwd shapes")
+    for t, n, ne in ((dW, "dW", 2 * F), (db, "db", 2), (dfeat, "dfeat", B * F), (mask, "mask", B * F)):
+        if t is not None:
+            _chk_f32(t, n)
+            _req(t.is_contiguous() and t.numel() == ne, n + " size")
+    _call("cgn_disc_head_bwd_f32", feat.device, _ptr(feat), ldf, _ptr(mask), _ptr(W), _ptr(dlogits), B, F, beta,
+          _ptr(dW), _ptr(db), _ptr(dfeat))
+
+
+def bernoulli(p1, u, c):
+    for t, n in ((p1, "p1"), (u, "u"), (c, "c")):
+        _chk_f32(t, n)
+        _req(t.is_contiguous() and t.numel() == p1.numel(), n + " size")
+    _call("cgn_bernoulli_f32", c.device, _ptr(p1), _ptr(u), p1.numel(), _ptr(c))
+    return c
+
+
+def act_maxpool(conv, B, P, act, feat, col0, arg):
+    """conv [B*P, Co] contiguous -> feat[:, col0:col0+Co], arg[:, col0:col0+Co] (int32)."""
+    _chk_f32(conv, "conv")
+    Co = conv.shape[1]
+    ldf = _rows2d(feat, "feat")
+    _req(conv.is_contiguous() and conv.shape[0] == B * P and feat.shape[0] == B and feat.shape[1] >= col0 + Co,
+         "act_maxpool shapes")
+    _req(arg.is_cuda and arg.dtype == torch.int32 and arg.is_contiguous() and arg.shape == feat.shape, "arg must be int32")
+    _call("cgn_act_maxpool_f32", feat.device, _ptr(conv), B, P, Co, act, _ptr(feat), ldf, col0, _ptr(arg), arg.stride(0))
+
+
+def _conv_widths(Ks, Cos, act, layout, W=None, dW=None, db=None):
+    cw = _lib.ConvWidths()
+    n = len(Ks)
+    _req(1 <= n <= 8, "1..8 widths")
+    col = 0
+    for i in range(n):
+        cw.K[i], cw.Co[i], cw.col0[i] = Ks[i], Cos[i], col
+        col += Cos[i]
+        for arr, name, ne in ((W, "W", None), (dW, "dW", None), (db, "db", Cos[i])):
+            if arr is not None and arr[i] is not None:
+                _chk_f32(arr[i], name)
+                _req(arr[i].is_contiguous(), name + " must be contiguous")
+                getattr(cw, name)[i] = arr[i].data_ptr()
+    cw.n, cw.F, cw.act, cw.layout = n, col, act, layout
+    return cw
+
+
+def conv_bwd_dx(Ks, Cos, act, layout, W, dfeat, feat, arg, B, L, E, dx, sent_stride):
+    """dx[b, 0:L, 0:E] (sentence stride given) from the pooled-feature gradient dfeat [B,F]."""
+    for i, w in enumerate(W):
+        _req(w.numel() == Cos[i] * Ks[i] * E and Ks[i] <= L, "conv weight %d size" % i)
+    cw = _conv_widths(Ks, Cos, act, layout, W=W)
+    _chk_f32(dfeat, "dfeat"), _chk_f32(dx, "dx")
+    _req(dfeat.is_contiguous() and dfeat.shape == (B, cw.F) and arg.dtype == torch.int32 and arg.is_contiguous()
+         and arg.shape == (B, cw.F), "conv_bwd_dx dfeat/arg shapes")
+    if feat is not None:
+        _req(feat.is_contiguous() and feat.shape == (B, cw.F), "feat shape")
+    nelem = dx.untyped_storage().nbytes() // 4 - dx.storage_offset()
+    _req(sent_stride >= L * E and (B - 1) * sent_stride + L * E <= nelem, "dx too small")
+    _call("cgn_conv_bwd_dx_f32", dx.device, C.byref(cw), _ptr(dfeat), _ptr(feat), _ptr(arg), B, L, E, _ptr(dx),
+          sent_stride)
+
+
+def conv_bwd_dw(Ks, Cos, act, layout, dW, db, dfeat, feat, arg, x, sent_stride, B, L, E, beta=0.0):
+    for i, w in enumerate(dW):
+        _req(w.numel() == Cos[i] * Ks[i] * E and Ks[i] <= L, "conv dW %d size" % i)
+    cw = _conv_widths(Ks, Cos, act, layout, dW=dW, db=db)
+    _chk_f32(dfeat, "dfeat"), _chk_f32(x, "x")
+    _req(dfeat.is_contiguous() and dfeat.shape == (B, cw.F) and arg.dtype == torch.int32 and arg.is_contiguous()
+         and arg.shape == (B, cw.F), "conv_bwd_dw dfeat/arg shapes")
+    if feat is not None:
+        _req(feat.is_contiguous() and feat.shape == (B, cw.F), "feat shape")
+    nelem = x.untyped_storage().nbytes() // 4 - x.storage_offset()
+    _req(sent_stride >= L * E and (B - 1) * sent_stride + L * E <= nelem, "x too small")
+    _call("cgn_conv_bwd_dw_f32", x.device, C.byref(cw), _ptr(dfeat), _ptr(feat), _ptr(arg), _ptr(x), sent_stride, B, L,
+          E, beta)
+
+
+def embedding_bwd(idx, dx, dtable, beta=0.0):
+    _chk_i64(idx, "idx"), _chk_f32(dx, "dx"), _chk_f32(dtable, "dtable")
+    V, E = dtable.shape
+    n = idx.numel()
+    _req(dx.is_contiguous() and dx.numel() == n * E and dtable.is_contiguous(), "embedding_bwd shapes")
+    _call("cgn_embedding_bwd_f32", dx.device, _ptr(idx), _ptr(dx), n, V, E, beta, _ptr(dtable))
+
+
+def lstm_seq_fwd(seqs, B, T, H):
+    """seqs: list of dicts(xg, xg_extra=None, w_hh, hbuf, cbuf, gates, reverse)."""
+    arr = (_lib.LstmFwdSeq * len(seqs))()
+    dev = seqs[0]["hbuf"].device
+    for i, s in enumerate(seqs):
+        for k, shape in (("xg", (B, T, 4 * H)), ("w_hh", (4 * H, H)), ("hbuf", (B, T + 1, H)), ("cbuf", (B, T + 1, H)),
+                         ("gates", (B, T, 4 * H))):
+            _chk_f32(s[k], k)
+            _req(s[k].is_contiguous() and tuple(s[k].shape) == shape, "lstm %s must be contiguous %s" % (k, shape))
+        ex = s.get("xg_extra")
+        if ex is not None:
+            _chk_f32(ex, "xg_extra")
+            _req(ex.is_contiguous() and tuple(ex.shape) == (B, 4 * H), "xg_extra must be [B,4H]")
+        arr[i].xg, arr[i].xg_extra, arr[i].w_hh = s["xg"].data_ptr(), (ex.data_ptr() if ex is not None else None), \
+            s["w_hh"].data_ptr()
+        arr[i].hbuf, arr[i].cbuf, arr[i].gates = s["hbuf"].data_ptr(), s["cbuf"].data_ptr(), s["gates"].data_ptr()
+        arr[i].reverse = 1 if s.get("reverse") else 0
+    _call("cgn_lstm_seq_fwd_f32", dev, arr, len(seqs), B, T, H)
+
+
+def lstm_seq_bwd(seqs, B, T, H):
+    """seqs: list of dicts(w_hh_t, cbuf, gates, dgates, dc_state, dh_ext=None (+dh_bs, dh_ts), dh_seed=None, reverse)."""
+    arr = (_lib.LstmBwdSeq * len(seqs))()
+    dev = seqs[0]["dgates"].device
+    for i, s in enumerate(seqs):
+        for k, shape in (("w_hh_t", (H, 4 * H)), ("cbuf", (B, T + 1, H)), ("gates", (B, T, 4 * H)),
+                         ("dgates", (B, T, 4 * H)), ("dc_state", (B, H))):
+            _chk_f32(s[k], k)
+            _req(s[k].is_contiguous() and tuple(s[k].shape) == shape, "lstm %s must be contiguous %s" % (k, shape))
+        ext, seed = s.get("dh_ext"), s.get("dh_seed")
+        if ext is not None:
+            _chk_f32(ext, "dh_ext")
+            bs, ts = int(s["dh_bs"]), int(s["dh_ts"])
+            nelem = ext.untyped_storage().nbytes() // 4 - ext.storage_offset()
+            _req(bs >= 0 and ts >= 0 and (B - 1) * bs + (T - 1) * ts + H <= nelem, "dh_ext addressing out of range")
+            arr[i].dh_bs, arr[i].dh_ts = bs, ts
+        if seed is not None:
+            _chk_f32(seed, "dh_seed")
+            _req(seed.is_contiguous() and tuple(seed.shape) == (B, H), "dh_seed must be [B,H]")
+        arr[i].w_hh_t, arr[i].cbuf, arr[i].gates = s["w_hh_t"].data_ptr(), s["cbuf"].data_ptr(), s["gates"].data_ptr()
+        arr[i].dh_ext = ext.data_ptr() if ext is not None else None
+        arr[i].dh_seed = seed.data_ptr() if seed is not None else None
+        arr[i].dgates, arr[i].dc_state = s["dgates"].data_ptr(), s["dc_state"].data_ptr()
+        arr[i].reverse = 1 if s.get("reverse") else 0
+    _call("cgn_lstm_seq_bwd_f32", dev, arr, len(seqs), B, T, H)
+
+
+def lincomb(terms, out=None):
+    """out[0] = sum coef*src[0] over terms [(coef, tensor), ...] (<= 4): scalar loss totals, on device."""
+    n = len(terms)
+    _req(1 <= n <= 4, "1..4 terms")
+    dev = terms[0][1].device
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for _, t in terms])
+    coefs = (C.c_float * n)(*[float(c) for c, _ in terms])
+    for _, t in terms:
+        _chk_f32(t, "term")
+        _req(t.numel() >= 1, "term must hold a scalar")
+    _call("cgn_lincomb_f32", dev, n, ptrs, coefs, _ptr(out))
+    return out
