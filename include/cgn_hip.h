@@ -177,6 +177,10 @@ int cgn_embedding_bwd_f32(void* stream, const int64_t* idx, const float* dx, int
 /* dst[r,c] = scale*src[r,c] + beta*dst[r,c] (strided rows). */
 int cgn_copy2d_f32(void* stream, const float* src, int64_t lds, float* dst, int64_t ldd, int32_t rows, int32_t cols,
                    float scale, float beta);
+/* dst[b,t,0:H] = src[b,t,0:H] + beta*dst[b,t,0:H] with independent batch/time strides (LSTM history slots <->
+ * batch-first tensors; s_ts = 0 broadcasts over t, the zc tiling of model/generator.py:54). */
+int cgn_copy3d_f32(void* stream, const float* src, int64_t s_bs, int64_t s_ts, float* dst, int64_t d_bs, int64_t d_ts,
+                  int32_t B, int32_t T, int32_t H, float beta);
 /* dst[cols, rows] = src[rows, cols]ᵀ (dense). */
 int cgn_transpose_f32(void* stream, const float* src, int32_t rows, int32_t cols, float* dst);
 /* out[i, 0:E] = table[idx[i], :] * mask[i, :] (nn.Embedding lookups of the frozen word table,
@@ -216,6 +220,14 @@ int cgn_disc_head_bwd_f32(void* stream, const float* feat, int64_t ldf, const fl
 /* c = (u < p1) — t.bernoulli(softmax[:,1]) with the uniform draw given (model/cgn.py:170). */
 int cgn_bernoulli_f32(void* stream, const float* p1, const float* u, int32_t n, float* c);
 int cgn_fill_f32(void* stream, float* p, int64_t n, float v);
+/* out[i] = (int64) x[i] — `c.long()` (model/cgn.py:1117). */
+int cgn_float_to_index_f32(void* stream, const float* x, int32_t n, int64_t* out);
+/* z-reconstruction loss (model/cgn.py:47-57,1134-1137): mulv1 = [mu|logvar] of the first encoder pass (constants),
+ * mulv2 of the second pass; z_loss[0] = sum_b dist_b / B; dmulv2 = weight * d z_loss / d mulv2. */
+int cgn_mahalanobis_f32(void* stream, const float* mulv1, const float* mulv2, int32_t B, int32_t Z, float weight,
+                        float* z_loss, float* dmulv2);
+/* out[i] = a[i]*b[i] (explicit dropout masks, model/generator.py:52). */
+int cgn_mul_f32(void* stream, const float* a, const float* b, float* out, int64_t n);
 /* out[0] = sum_i coef[i]*src[i][0], n <= 4 (loss totals of model/cgn.py:329,334,1151-1152); src, coef: host arrays. */
 int cgn_lincomb_f32(void* stream, int32_t n, const float* const* src, const float* coef, float* out);
 

@@ -26,6 +26,21 @@ __global__ __launch_bounds__(PW_NT) void copy2d_kernel(const float* __restrict__
     }
 }
 
+// ---- strided [B,T,H] copy (LSTM history slots <-> batch-first outputs) ------------------------------------------
+__global__ __launch_bounds__(PW_NT) void copy3d_kernel(const float* __restrict__ src, long s_bs, long s_ts,
+                                                       float* __restrict__ dst, long d_bs, long d_ts, int B, int T,
+                                                       int H, float beta) {
+    const long total = (long)B * T * H;
+    for (long i = (long)blockIdx.x * PW_NT + threadIdx.x; i < total; i += (long)gridDim.x * PW_NT) {
+        const int h = (int)(i % H);
+        const long bt = i / H;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        float* d = dst + (long)b * d_bs + (long)t * d_ts + h;
+        const float v = src[(long)b * s_bs + (long)t * s_ts + h];
+        *d = (beta != 0.f) ? v + beta * (*d) : v;
+    }
+}
+
 // ---- 2-D transpose through LDS --------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int rows, int cols,
                                                         float* __restrict__ dst) {
@@ -288,6 +303,53 @@ __global__ __launch_bounds__(PW_NT) void bernoulli_kernel(const float* __restric
     if (i < n) c[i] = (u[i] < p1[i]) ? 1.f : 0.f;
 }
 
+// out = a * b elementwise over [R, C] (explicit dropout masks on the modular path)
+__global__ __launch_bounds__(PW_NT) void mul2d_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * PW_NT + threadIdx.x; i < n; i += (long)gridDim.x * PW_NT) out[i] = a[i] * b[i];
+}
+
+// labels = (int64) c  — `c.long()` of model/cgn.py:1117
+__global__ __launch_bounds__(PW_NT) void float_to_index_kernel(const float* __restrict__ x, int n,
+                                                               int64_t* __restrict__ out) {
+    const int i = blockIdx.x * PW_NT + threadIdx.x;
+    if (i < n) out[i] = (int64_t)x[i];
+}
+
+// z-reconstruction loss (model/cgn.py:47-57, :1134-1137): with (mu1, std1) constants and (mu2, logvar2) from the
+// second encoder pass, dist_b = sqrt(sum_z (mu1-mu2)^2 / ((std1+std2)/2)), z_loss = sum_b dist_b / B;
+// dmulv2 = weight * d z_loss / d[mu2 | logvar2]. One wave per sentence, single workgroup (B is small).
+__global__ __launch_bounds__(256) void mahalanobis_kernel(const float* __restrict__ mulv1, const float* __restrict__ mulv2,
+                                                          int B, int Z, float weight, float* __restrict__ z_loss,
+                                                          float* __restrict__ dmulv2) {
+    __shared__ float red[8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float total = 0.f;
+    for (int b = wave; b < B; b += 4) {
+        const float* m1 = mulv1 + (long)b * 2 * Z;
+        const float* m2 = mulv2 + (long)b * 2 * Z;
+        float acc = 0.f;
+        for (int k = lane; k < Z; k += 64) {
+            const float d = m1[k] - m2[k];
+            const float s = 0.5f * (expf(0.5f * m1[Z + k]) + expf(0.5f * m2[Z + k]));
+            acc += d * d / s;
+        }
+        acc = wave_sum(acc);
+        const float dist = sqrtf(acc);
+        if (lane == 0) total += dist;
+        const float inv = (dist > 0.f) ? weight / ((float)B * dist) : 0.f;  // d sqrt at 0 is undefined; emit 0
+        for (int k = lane; k < Z; k += 64) {
+            const float d = m1[k] - m2[k];
+            const float sd2 = expf(0.5f * m2[Z + k]);
+            const float s = 0.5f * (expf(0.5f * m1[Z + k]) + sd2);
+            dmulv2[(long)b * 2 * Z + k] = -d / s * inv;
+            dmulv2[(long)b * 2 * Z + Z + k] = -(d * d) / (4.f * s * s) * inv * 0.5f * sd2;
+        }
+    }
+    total = block_sum<256>(total, red);
+    if (threadIdx.x == 0) z_loss[0] = total / (float)B;
+}
+
 struct LinComb {
     const float* src[4];
     float coef[4];
@@ -318,6 +380,17 @@ extern "C" int cgn_copy2d_f32(void* stream, const float* src, int64_t lds_, floa
     CGN_CHECK_ARG(src && dst && lds_ >= cols && ldd >= cols);
     hipLaunchKernelGGL(copy2d_kernel, dim3(pw_blocks((long)rows * cols)), dim3(PW_NT), 0, S_(stream), src, (long)lds_,
                        dst, (long)ldd, rows, cols, scale, beta);
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}
+
+extern "C" int cgn_copy3d_f32(void* stream, const float* src, int64_t s_bs, int64_t s_ts, float* dst, int64_t d_bs,
+                              int64_t d_ts, int32_t B, int32_t T, int32_t H, float beta) {
+    CGN_CHECK_ARG(B >= 0 && T >= 0 && H >= 0);
+    if (B == 0 || T == 0 || H == 0) return CGN_OK;
+    CGN_CHECK_ARG(src && dst && (s_ts >= H || s_ts == 0) && d_ts >= H && s_bs >= 0 && d_bs >= 0);  // s_ts 0 = broadcast over t
+    hipLaunchKernelGGL(copy3d_kernel, dim3(pw_blocks((long)B * T * H)), dim3(PW_NT), 0, S_(stream), src, (long)s_bs,
+                       (long)s_ts, dst, (long)d_bs, (long)d_ts, B, T, H, beta);
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }
@@ -485,6 +558,33 @@ extern "C" int cgn_lincomb_f32(void* stream, int32_t n, const float* const* src,
         if (i < n) CGN_CHECK_ARG(src[i] != nullptr);
     }
     hipLaunchKernelGGL(lincomb_kernel, dim3(1), dim3(64), 0, S_(stream), lc, out);
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}
+
+extern "C" int cgn_mul_f32(void* stream, const float* a, const float* b, float* out, int64_t n) {
+    CGN_CHECK_ARG(n >= 0);
+    if (n == 0) return CGN_OK;
+    CGN_CHECK_ARG(a && b && out);
+    hipLaunchKernelGGL(mul2d_kernel, dim3(pw_blocks(n)), dim3(PW_NT), 0, S_(stream), a, b, out, (long)n);
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}
+
+extern "C" int cgn_float_to_index_f32(void* stream, const float* x, int32_t n, int64_t* out) {
+    CGN_CHECK_ARG(n >= 0);
+    if (n == 0) return CGN_OK;
+    CGN_CHECK_ARG(x && out);
+    hipLaunchKernelGGL(float_to_index_kernel, dim3(cgn_cdiv(n, PW_NT)), dim3(PW_NT), 0, S_(stream), x, n, out);
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}
+
+extern "C" int cgn_mahalanobis_f32(void* stream, const float* mulv1, const float* mulv2, int32_t B, int32_t Z,
+                                   float weight, float* z_loss, float* dmulv2) {
+    CGN_CHECK_ARG(B > 0 && Z > 0);
+    CGN_CHECK_ARG(mulv1 && mulv2 && z_loss && dmulv2);
+    hipLaunchKernelGGL(mahalanobis_kernel, dim3(1), dim3(256), 0, S_(stream), mulv1, mulv2, B, Z, weight, z_loss, dmulv2);
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }

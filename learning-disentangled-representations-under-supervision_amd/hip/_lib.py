@@ -79,6 +79,9 @@ PROTOTYPES = {
                                     c_i32, c_f32]),
     "cgn_embedding_bwd_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_f32, c_ptr]),
     "cgn_copy2d_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_f32, c_f32]),
+    "cgn_copy3d_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_i32, c_i32, c_i32, c_f32]),
+    "cgn_float_to_index_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_ptr]),
+    "cgn_mahalanobis_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_f32, c_ptr, c_ptr]),
     "cgn_transpose_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_ptr]),
     "cgn_gather_rows_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i64]),
     "cgn_highway_gate_fwd_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i64]),
@@ -95,6 +98,7 @@ PROTOTYPES = {
                                       c_ptr]),
     "cgn_bernoulli_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_i32, c_ptr]),
     "cgn_fill_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_f32]),
+    "cgn_mul_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64]),
     "cgn_lincomb_f32": (c_i32, [c_ptr, c_i32, C.POINTER(c_ptr), C.POINTER(c_f32), c_ptr]),
 }
 

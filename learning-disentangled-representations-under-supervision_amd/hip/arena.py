@@ -23,9 +23,6 @@ class ParamArena:
         self.size = off
         self.p = torch.zeros(off, dtype=torch.float32, device=device)
         self.g = torch.zeros(off, dtype=torch.float32, device=device)
-        self.m = torch.zeros(off, dtype=torch.float32, device=device)
-        self.v = torch.zeros(off, dtype=torch.float32, device=device)
-        self.step = 0
         self.params, self.grads = {}, {}
         for n, p in named_params:
             o, ne, shape = self.offsets[n]
@@ -46,7 +43,20 @@ class ParamArena:
         if self.size:
             ops.fill(self.g, 0.0)
 
-    def adam_step(self, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
+    def new_adam(self):
+        """A fresh optimizer state for this group (the reference creates a new torch Adam per step-closure factory)."""
+        return AdamState(self)
+
+
+class AdamState:
+    def __init__(self, arena):
+        self.arena = arena
+        self.m = torch.zeros(arena.size, dtype=torch.float32, device=arena.p.device)
+        self.v = torch.zeros(arena.size, dtype=torch.float32, device=arena.p.device)
+        self.step = 0
+
+    def apply(self, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
         self.step += 1
-        if self.size:
-            ops.adam(self.p, self.g, self.m, self.v, lr, self.step, betas[0], betas[1], eps, grad_scale)
+        a = self.arena
+        if a.size:
+            ops.adam(a.p, a.g, self.m, self.v, lr, self.step, betas[0], betas[1], eps, grad_scale)

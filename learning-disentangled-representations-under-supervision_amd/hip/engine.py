@@ -40,13 +40,10 @@ def linear_bwd(x2d, W, dy, dW, db, dx=None, beta=0.0, dx_beta=0.0):
 # ------------------------------------------------------------------------------------------------------------------
 # char-TDNN (selfModules/tdnn.py:18-48) incl. the char-embedding lookup (selfModules/embedding.py:44-51)
 # ------------------------------------------------------------------------------------------------------------------
-def tdnn_fwd(char_idx, char_table, kernels):
-    """char_idx [N, W] int64 -> feat [N, S] (contiguous). kernels: list of [od, Cc, kW]."""
-    N, Wl = char_idx.shape
-    CV, Cc = char_table.shape
-    dev = char_table.device
-    xw = _new((N * Wl, Cc), dev)
-    ops.gather_rows(char_table, char_idx.reshape(-1), xw)
+def tdnn_conv_fwd(xw, N, Wl, kernels):
+    """xw [N*W, Cc] embedded characters -> feat [N, S] (contiguous). kernels: list of [od, Cc, kW]."""
+    Cc = xw.shape[1]
+    dev = xw.device
     S = sum(k.shape[0] for k in kernels)
     feat = _new((N, S), dev)
     arg = _new((N, S), dev, torch.int32)
@@ -63,19 +60,38 @@ def tdnn_fwd(char_idx, char_table, kernels):
                  b_k=Axis(kW, Cc, 1), b_n=Axis(Cc * kW, 0, 0))
         ops.act_maxpool(conv, N, P, ACT_TANH, feat, col, arg)
         col += od
-    return feat, dict(xw=xw, feat=feat, arg=arg, char_idx=char_idx, N=N, W=Wl, Cc=Cc)
+    return feat, dict(xw=xw, feat=feat, arg=arg, N=N, W=Wl, Cc=Cc)
 
 
-def tdnn_bwd(saved, kernels, dfeat, dkernels, dchar_table, beta=0.0):
-    """dfeat [N,S] contiguous -> kernel grads and the char-embedding table gradient."""
+def tdnn_conv_bwd(saved, kernels, dfeat, dkernels, need_dx, beta=0.0):
+    """dfeat [N,S] contiguous -> kernel grads (into dkernels) and, if asked, d(xw) [N*W, Cc]."""
     N, Wl, Cc = saved["N"], saved["W"], saved["Cc"]
     Ks = [k.shape[2] for k in kernels]
     Cos = [k.shape[0] for k in kernels]
-    ops.conv_bwd_dw(Ks, Cos, ACT_TANH, 1, dkernels, None, dfeat, saved["feat"], saved["arg"], saved["xw"], Wl * Cc, N,
-                    Wl, Cc, beta=beta)
+    if dkernels is not None:
+        ops.conv_bwd_dw(Ks, Cos, ACT_TANH, 1, dkernels, None, dfeat, saved["feat"], saved["arg"], saved["xw"], Wl * Cc,
+                        N, Wl, Cc, beta=beta)
+    if not need_dx:
+        return None
     dxw = _new((N * Wl, Cc), dfeat.device)
     ops.conv_bwd_dx(Ks, Cos, ACT_TANH, 1, list(kernels), dfeat, saved["feat"], saved["arg"], N, Wl, Cc, dxw, Wl * Cc)
-    ops.embedding_bwd(saved["char_idx"].reshape(-1), dxw, dchar_table, beta=beta)
+    return dxw
+
+
+def tdnn_fwd(char_idx, char_table, kernels):
+    """char_idx [N, W] int64 -> feat [N, S]: char-embedding lookup (selfModules/embedding.py:44-49) + TDNN."""
+    N, Wl = char_idx.shape
+    xw = _new((N * Wl, char_table.shape[1]), char_table.device)
+    flat = char_idx.reshape(-1)
+    ops.gather_rows(char_table, flat, xw)
+    feat, saved = tdnn_conv_fwd(xw, N, Wl, kernels)
+    saved["char_idx"] = flat
+    return feat, saved
+
+
+def tdnn_bwd(saved, kernels, dfeat, dkernels, dchar_table, beta=0.0):
+    dxw = tdnn_conv_bwd(saved, kernels, dfeat, dkernels, need_dx=True, beta=beta)
+    ops.embedding_bwd(saved["char_idx"], dxw, dchar_table, beta=beta)
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -479,3 +479,41 @@ def lincomb(terms, out=None):
         _req(t.numel() >= 1, "term must hold a scalar")
     _call("cgn_lincomb_f32", dev, n, ptrs, coefs, _ptr(out))
     return out
+
+
+def copy3d(src, dst, beta=0.0):
+    """dst[b,t,:] = src[b,t,:] + beta*dst[b,t,:] for [B,T,H] views with unit last stride (any batch/time strides)."""
+    _chk_f32(src, "src"), _chk_f32(dst, "dst")
+    _req(src.dim() == 3 and src.shape == dst.shape and src.stride(2) == 1 and dst.stride(2) == 1, "copy3d shapes")
+    B, T, H = src.shape
+    _call("cgn_copy3d_f32", dst.device, _ptr(src), src.stride(0), src.stride(1), _ptr(dst), dst.stride(0),
+          dst.stride(1), B, T, H, beta)
+    return dst
+
+
+def add3d(src, dst):
+    return copy3d(src, dst, beta=1.0)
+
+
+def float_to_index(x, out):
+    _chk_f32(x, "x"), _chk_i64(out, "out")
+    _req(x.is_contiguous() and out.numel() == x.numel(), "float_to_index sizes")
+    _call("cgn_float_to_index_f32", x.device, _ptr(x), x.numel(), _ptr(out))
+    return out
+
+
+def mahalanobis(mulv1, mulv2, weight, z_loss, dmulv2):
+    B, Z2 = mulv1.shape
+    for t, n in ((mulv1, "mulv1"), (mulv2, "mulv2"), (dmulv2, "dmulv2"), (z_loss, "z_loss")):
+        _chk_f32(t, n)
+        _req(t.is_contiguous(), n + " must be contiguous")
+    _req(mulv2.shape == mulv1.shape and dmulv2.shape == mulv1.shape and z_loss.numel() == 1, "mahalanobis shapes")
+    _call("cgn_mahalanobis_f32", mulv1.device, _ptr(mulv1), _ptr(mulv2), B, Z2 // 2, weight, _ptr(z_loss), _ptr(dmulv2))
+
+
+def mul2d(a, b, out):
+    for t, n in ((a, "a"), (b, "b"), (out, "out")):
+        _chk_f32(t, n)
+        _req(t.is_contiguous() and t.numel() == a.numel(), n + " must be contiguous, same size")
+    _call("cgn_mul_f32", out.device, _ptr(a), _ptr(b), _ptr(out), a.numel())
+    return out

@@ -1,0 +1,359 @@
+"""The fused CGN wake-sleep training step on MI355X: discriminator step, c inference, encoder/generator step.
+
+This is the hot path named by BASELINE.json. It reproduces, without autograd, the exact gradient routing of the
+reference's step closures (model/cgn.py:269-341 and :1049-1154):
+  * z is a detached leaf: the generator-side losses reach the encoder only through g = d(79*CE + recon)/dz;
+  * the CE and reconstruction backward passes of the reference are summed into ONE pass over the logits
+    (dlogits = CE part + soft-embedding part, fused into the dOut·Eᵀ GEMM epilogue, written in place over the logits);
+  * the generator's Adam step happens before the encoder's backward; the discriminator is frozen in this step and
+    only passes gradients through to the soft embeddings; the word-embedding table never gets a gradient;
+  * encoder gradients = d(kld_coef*KLD)/dθ + (dz_out/dθ)ᵀ g.
+Parameter gradients land in the flat arenas (hip/arena.py); one Adam kernel per optimizer group.
+"""
+import torch
+
+from . import engine, ops
+from ._lib import ACT_RELU, Axis
+from .arena import ParamArena
+
+LIN = Axis(1, 0, 0)
+
+
+def _new(shape, dev, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
+class CGNStep:
+    def __init__(self, model, allreduce=None, world_size=1):
+        """model: Controlled_Generation_Sentence on a HIP device. allreduce(flat_grad_tensor) is called on each
+        optimizer group's gradient arena right before its Adam step (data parallelism); gradients are then scaled by
+        1/world_size inside the Adam kernel."""
+        self.model = model
+        self.cfg = model.config
+        named = dict(model.named_parameters())
+        dev = named["e2mu.weight"].device
+        if dev.type != "cuda":
+            raise RuntimeError("CGNStep needs the model on an MI355X (HIP) device: call model.cuda() first")
+        self.dev = dev
+        groups = {"disc": [], "gen": [], "enc": []}
+        for n, p in named.items():
+            if n == "embedding.word_embed.weight":
+                continue  # frozen constant (selfModules/embedding.py:23)
+            if n.startswith("sentiment_discriminator."):
+                groups["disc"].append((n, p))
+            elif n.startswith("generator."):
+                groups["gen"].append((n, p))
+            else:
+                groups["enc"].append((n, p))  # cgn.py:676-683: encoder + embedding + e2mu + e2logvar
+        self.named_groups = groups
+        self.arenas = {k: ParamArena(v, dev) for k, v in groups.items()}
+        self.P = {n: p.data for n, p in named.items()}
+        self.G = {}
+        for a in self.arenas.values():
+            self.G.update(a.grads)
+        self.allreduce = allreduce
+        self.world_size = world_size
+        cfg = self.cfg
+        self.n_hw = model.encoder.hw1.num_layers
+        self.Ks = list(cfg.sentiment_kernel_size)
+        self.Cos = [cfg.sentiment_kernel_num] * len(self.Ks)
+
+    def valid(self):
+        return all(self.arenas[k].owns(v) for k, v in self.named_groups.items())
+
+    # -------------------------------------------------------------------------------------------------------------
+    def new_optimizer(self, group):
+        """Fresh Adam state for 'disc' | 'enc' | 'gen' (cgn.py:267, :1046-1047 create torch Adam objects likewise)."""
+        return self.arenas[group].new_adam()
+
+    def _optim_step(self, state):
+        a = state.arena
+        if self.allreduce is not None and self.world_size > 1:
+            self.allreduce(a.g)
+        state.apply(self.cfg.learning_rate, grad_scale=1.0 / self.world_size)
+
+    def _hw_layers(self, table):
+        pre = "encoder.hw1."
+        return [dict(nw=table[pre + "nonlinear_module_%d-0" % l], nb=table[pre + "nonlinear_module_%d-1" % l],
+                     lw=table[pre + "linear_module_%d-0" % l], lb=table[pre + "linear_module_%d-1" % l],
+                     gw=table[pre + "gate_module_%d-0" % l], gb=table[pre + "gate_module_%d-1" % l])
+                for l in range(self.n_hw)]
+
+    def _conv_params(self, table):
+        w = [table["sentiment_discriminator.convs1.%d.weight" % i] for i in range(len(self.Ks))]
+        b = [table["sentiment_discriminator.convs1.%d.bias" % i] for i in range(len(self.Ks))]
+        return w, b
+
+    def _tdnn_kernels(self, table):
+        return [table["embedding.TDNN.TDNN_kernel-%d" % i] for i in range(len(self.cfg.kernels))]
+
+    # -------------------------------------------------------------------------------------------------------------
+    # discriminator forward on token ids (word table lookup + text-CNN features)
+    # -------------------------------------------------------------------------------------------------------------
+    def _disc_features_from_ids(self, ids):
+        P, E = self.P, self.cfg.word_embed_size
+        B, L = ids.shape
+        emb = _new((B * L, E), self.dev)
+        ops.gather_rows(P["embedding.word_embed.weight"], ids.reshape(-1), emb)
+        cw, cb = self._conv_params(P)
+        feat, arg = engine.textcnn_features_fwd(emb, B, L, E, L * E, cw, cb)
+        return emb, feat, arg
+
+    def infer_c(self, enc_word, uniform):
+        """model/cgn.py:134-172: c ~ Bernoulli(softmax(D(emb(x)))[:,1]) with the uniform draw given. Returns (c, p1)."""
+        P = self.P
+        B = enc_word.shape[0]
+        _, feat, _ = self._disc_features_from_ids(enc_word)
+        logits, p1, c = _new((B, 2), self.dev), _new((B,), self.dev), _new((B,), self.dev)
+        ops.disc_head(feat, P["sentiment_discriminator.fc1.weight"], P["sentiment_discriminator.fc1.bias"], logits,
+                      p1=p1)
+        ops.bernoulli(p1, uniform, c)
+        return c, p1
+
+    def disc_train(self, opt, x_labelled, y_labelled, x_generated, c_generated, mask_labelled=None,
+                   mask_generated=None, train=True, capture=None):
+        """One discriminator step, model/cgn.py:269-341. Returns the 5-tuple of :341 as 1-element device tensors."""
+        cfg, P, G = self.cfg, self.P, self.G
+        E = cfg.word_embed_size
+        W, b = P["sentiment_discriminator.fc1.weight"], P["sentiment_discriminator.fc1.bias"]
+        dW, db = G["sentiment_discriminator.fc1.weight"], G["sentiment_discriminator.fc1.bias"]
+        dcw, dcb = self._conv_params(G)
+        passes = ((x_labelled, y_labelled, mask_labelled, 1.0, 0.0),
+                  (x_generated, c_generated, mask_generated, cfg.lambda_u, cfg.lambda_u * cfg.beta))
+        stats_all = []
+        for i, (x, y, mask, w_ce, w_ent) in enumerate(passes):
+            B, L = x.shape
+            emb, feat, arg = self._disc_features_from_ids(x)
+            logits, dlog, stats = _new((B, 2), self.dev), _new((B, 2), self.dev), _new((2,), self.dev)
+            ops.disc_head(feat, W, b, logits, mask=mask, y=y, w_ce=w_ce, w_ent=w_ent, dlogits=dlog, stats=stats)
+            stats_all.append(stats)
+            if not train:
+                continue
+            beta = 0.0 if i == 0 else 1.0
+            dfeat = _new(tuple(feat.shape), self.dev)
+            ops.disc_head_bwd(feat, W, dlog, mask=mask, beta=beta, dW=dW, db=db, dfeat=dfeat)
+            ops.conv_bwd_dw(self.Ks, self.Cos, ACT_RELU, 0, dcw, dcb, dfeat, None, arg, emb, L * E, B, L, E, beta=beta)
+        if train:
+            if capture is not None:
+                capture["disc_grads"] = {n: g.clone() for n, g in self.arenas["disc"].grads.items()}
+            self._optim_step(opt)
+        ce_l, ce_g, ent = stats_all[0][0:1], stats_all[1][0:1], stats_all[1][1:2]
+        gen_loss = ops.lincomb([(1.0, ce_g), (cfg.beta, ent)])  # :329
+        total = ops.lincomb([(1.0, ce_l), (cfg.lambda_u, gen_loss)])  # :334
+        return total, ce_l, gen_loss, ce_g, ent
+
+    # -------------------------------------------------------------------------------------------------------------
+    # encoder forward (embedding -> highway -> biLSTM -> mu/logvar); `x_words` None => word part gathered from ids
+    # -------------------------------------------------------------------------------------------------------------
+    def _encoder_fwd(self, enc_in, B, L):
+        cfg, P = self.cfg, self.P
+        He, Z = cfg.encoder_rnn_size, cfg.latent_variable_size
+        N = B * L
+        hw_out, hw_saved = engine.highway_fwd(enc_in, self._hw_layers(P))
+        sf, sr = engine.LstmSeq(B, L, He, self.dev, False), engine.LstmSeq(B, L, He, self.dev, True)
+        for s, sfx in ((sf, ""), (sr, "_reverse")):
+            ops.gemm(hw_out, P["encoder.rnn.weight_ih_l0" + sfx].t(), s.xg.view(N, 4 * He),
+                     bias0=P["encoder.rnn.bias_ih_l0" + sfx], bias1=P["encoder.rnn.bias_hh_l0" + sfx])
+            s.set_initial()
+        engine.lstm_run_fwd([sf, sr], [P["encoder.rnn.weight_hh_l0"], P["encoder.rnn.weight_hh_l0_reverse"]])
+        ctx = _new((B, 2 * He), self.dev)
+        ops.copy2d(sf.c_final(), ctx[:, :He])
+        ops.copy2d(sr.c_final(), ctx[:, He:])
+        mulv = _new((B, 2 * Z), self.dev)
+        ops.gemm(ctx, P["e2mu.weight"].t(), mulv[:, :Z], bias0=P["e2mu.bias"])
+        ops.gemm(ctx, P["e2logvar.weight"].t(), mulv[:, Z:], bias0=P["e2logvar.bias"])
+        return dict(hw_out=hw_out, hw_saved=hw_saved, sf=sf, sr=sr, ctx=ctx, mulv=mulv, B=B, L=L)
+
+    def _encoder_bwd(self, es, dmulv, param_grads):
+        """Backward of _encoder_fwd from d[mu|logvar]. param_grads True: write encoder parameter grads (G);
+        returns d(enc_in) [N, Din]."""
+        cfg, P, G = self.cfg, self.P, self.G
+        He, Z = cfg.encoder_rnn_size, cfg.latent_variable_size
+        B, L = es["B"], es["L"]
+        N = B * L
+        ctx = es["ctx"]
+        dctx = _new((B, 2 * He), self.dev)
+        dmu, dlv = dmulv[:, :Z], dmulv[:, Z:]
+        if param_grads:
+            engine.linear_bwd(ctx, P["e2mu.weight"], dmu, G["e2mu.weight"], G["e2mu.bias"], dx=dctx)
+            engine.linear_bwd(ctx, P["e2logvar.weight"], dlv, G["e2logvar.weight"], G["e2logvar.bias"], dx=dctx,
+                              dx_beta=1.0)
+        else:
+            ops.gemm(dmu, P["e2mu.weight"], dctx)
+            ops.gemm(dlv, P["e2logvar.weight"], dctx, beta=1.0)
+        dcf, dcr = _new((B, He), self.dev), _new((B, He), self.dev)
+        ops.copy2d(dctx[:, :He], dcf)
+        ops.copy2d(dctx[:, He:], dcr)
+        sf, sr = es["sf"], es["sr"]
+        dgf, dgr = engine.lstm_run_bwd([sf, sr], [P["encoder.rnn.weight_hh_l0"], P["encoder.rnn.weight_hh_l0_reverse"]],
+                                       [None, None], [None, None], [dcf, dcr])
+        hw_out = es["hw_out"]
+        Din = hw_out.shape[1]
+        dhw = _new((N, Din), self.dev)
+        for i, (s, dg, sfx) in enumerate(((sf, dgf, ""), (sr, dgr, "_reverse"))):
+            if param_grads:
+                dg2 = engine.lstm_param_grads(s, dg, (hw_out, Axis(Din, 0, 0)), G["encoder.rnn.weight_ih_l0" + sfx],
+                                              G["encoder.rnn.weight_hh_l0" + sfx], G["encoder.rnn.bias_ih_l0" + sfx],
+                                              G["encoder.rnn.bias_hh_l0" + sfx])
+            else:
+                dg2 = dg.view(N, 4 * He)
+            ops.gemm(dg2, P["encoder.rnn.weight_ih_l0" + sfx], dhw, beta=(0.0 if i == 0 else 1.0))
+        return engine.highway_bwd(es["hw_saved"], self._hw_layers(P), dhw, self._hw_layers(G) if param_grads else None,
+                                  need_dx=True)
+
+    # -------------------------------------------------------------------------------------------------------------
+    def enc_gen_train(self, opts, enc_word, enc_char, dec_word, target, c_target, eps, kld_coeff, temperature,
+                      gen_drop_mask=None, calc_z_loss=True, capture=None, train=True, use_disc=True, joint=False):
+        """One encoder/generator step, model/cgn.py:1049-1154. All tensor arguments live on the device:
+        enc_word [B,L], enc_char [B,L,W], dec_word [B,T], target [B,T] int64; c_target [B] or [B,C] float;
+        eps [B,Z] (the randn of cgn.py:96); gen_drop_mask None or [B,T,E] (explicit, scaled word-dropout mask).
+        Returns (cross_entropy, kld, z_loss, c_loss, total_encoder_loss, total_generator_loss) device scalars."""
+        cfg, P, G, dev = self.cfg, self.P, self.G, self.dev
+        B, L = enc_word.shape
+        T = dec_word.shape[1]
+        E, S = cfg.word_embed_size, cfg.sum_depth
+        Din, Hg, Z, C, V = E + S, cfg.decoder_rnn_size, cfg.latent_variable_size, cfg.c_size, cfg.word_vocab_size
+        N, NT = B * L, B * T
+        Wl = cfg.max_word_len
+        inv_tau = 1.0 / float(temperature)
+        table = P["embedding.word_embed.weight"]
+        if L + 1 != T:
+            raise ValueError("generator sequence must be one longer than the encoder's (go/eos token)")
+        if L < max(self.Ks):
+            raise RuntimeError("Kernel size can't be greater than actual input size")
+
+        # ---- embedding (selfModules/embedding.py:29-55) --------------------------------------------------------
+        enc_in = _new((N, Din), dev)
+        ops.gather_rows(table, enc_word.reshape(-1), enc_in[:, :E])
+        tk = self._tdnn_kernels(P)
+        tfeat, tsaved = engine.tdnn_fwd(enc_char.reshape(N, Wl), P["embedding.char_embed.weight"], tk)
+        ops.copy2d(tfeat, enc_in[:, E:])
+        # ---- encode_for_z (cgn.py:83-103) + KLD (:1076) + [z,c] (:1080) ------------------------------------------
+        es = self._encoder_fwd(enc_in, B, L)
+        mulv = es["mulv"]
+        zc, std, kld = _new((B, Z + C), dev), _new((B, Z), dev), _new((1,), dev)
+        cvec = c_target.reshape(B, C)
+        ops.reparam_kld_fwd(mulv, eps, cvec, zc, std, kld)
+        # ---- generator (model/generator.py:45-64) --------------------------------------------------------------
+        gen_emb = _new((NT, E), dev)
+        ops.gather_rows(table, dec_word.reshape(-1), gen_emb,
+                        mask=None if gen_drop_mask is None else gen_drop_mask.reshape(NT, E))
+        g0, g1 = engine.LstmSeq(B, T, Hg, dev, False), engine.LstmSeq(B, T, Hg, dev, False)
+        Wih0 = P["generator.rnn.weight_ih_l0"]
+        ops.gemm(gen_emb, Wih0[:, :E].t(), g0.xg.view(NT, 4 * Hg), bias0=P["generator.rnn.bias_ih_l0"],
+                 bias1=P["generator.rnn.bias_hh_l0"])
+        zg = _new((B, 4 * Hg), dev)
+        ops.gemm(zc, Wih0[:, E:].t(), zg)  # the tiled [z,c] input contributes once per sentence
+        g0.xg_extra = zg
+        g0.set_initial()
+        engine.lstm_run_fwd([g0], [P["generator.rnn.weight_hh_l0"]])
+        h0, h0ax = g0.hout_operand()
+        ops.gemm(h0, P["generator.rnn.weight_ih_l1"].t(), g1.xg.view(NT, 4 * Hg), M=NT, K=Hg, a_m=h0ax, a_k=LIN,
+                 bias0=P["generator.rnn.bias_ih_l1"], bias1=P["generator.rnn.bias_hh_l1"])
+        g1.set_initial()
+        engine.lstm_run_fwd([g1], [P["generator.rnn.weight_hh_l1"]])
+        h1, h1ax = g1.hout_operand()
+        logits = _new((NT, V), dev)
+        ops.gemm(h1, P["generator.fc.weight"].t(), logits, M=NT, K=Hg, a_m=h1ax, a_k=LIN, bias0=P["generator.fc.bias"])
+        # ---- temperature softmax + CE (cgn.py:1086-1092) -------------------------------------------------------
+        tgt = target.reshape(-1)
+        lse, nll, ce = ops.softmax_nll_fwd(logits, tgt, inv_tau)
+        dummy = lse  # any valid device pointer for unused GEMM operands (K = 0)
+        need_soft = use_disc or calc_z_loss
+        c_loss, z_loss = _new((1,), dev), _new((1,), dev)
+        ops.fill(c_loss, 0.0)
+        ops.fill(z_loss, 0.0)
+        if need_soft:
+            # ---- soft embedding (cgn.py:1103-1108): softmax(logits/tau) @ E, probabilities formed in the A loader
+            out_emb = _new((NT, E), dev)
+            ops.gemm(logits, table, out_emb, a_exp=(inv_tau, lse))
+            d_out_emb = _new((NT, E), dev)
+            ops.fill(d_out_emb, 0.0)  # rows t = T-1 stay zero: out_embedding[:, :-1, :] (cgn.py:1108)
+        if use_disc:
+            # ---- c reconstruction through the frozen discriminator (cgn.py:1114-1120) ----------------------------
+            cw, cb = self._conv_params(P)
+            feat_d, arg_d = engine.textcnn_features_fwd(out_emb, B, L, E, T * E, cw, cb)  # rows t < L per sentence
+            fcw, fcb = P["sentiment_discriminator.fc1.weight"], P["sentiment_discriminator.fc1.bias"]
+            logits2, dlog2, stats2 = _new((B, 2), dev), _new((B, 2), dev), _new((2,), dev)
+            y_c = _new((B,), dev, torch.int64)
+            ops.float_to_index(cvec[:, 0].contiguous() if C > 1 else cvec.reshape(B), y_c)
+            ops.disc_head(feat_d, fcw, fcb, logits2, y=y_c, w_ce=cfg.lambda_c, dlogits=dlog2, stats=stats2)
+            c_loss = stats2[0:1]
+            if train:
+                dfeat_d = _new(tuple(feat_d.shape), dev)
+                ops.disc_head_bwd(feat_d, fcw, dlog2, dfeat=dfeat_d)
+                ops.conv_bwd_dx(self.Ks, self.Cos, ACT_RELU, 0, [w.view(w.shape[0], -1) for w in cw], dfeat_d, None,
+                                arg_d, B, L, E, d_out_emb, T * E)
+        if calc_z_loss:
+            # ---- z reconstruction through the encoder (cgn.py:1122-1137) ------------------------------------------
+            enc_in2 = _new((N, Din), dev)
+            ops.copy3d(out_emb.view(B, T, E)[:, :L], enc_in2.view(B, L, Din)[:, :, :E])
+            ops.copy2d(tfeat, enc_in2[:, E:])
+            es2 = self._encoder_fwd(enc_in2, B, L)
+            dmulv2 = _new((B, 2 * Z), dev)
+            ops.mahalanobis(mulv, es2["mulv"], cfg.lambda_z, z_loss, dmulv2)
+            if train:
+                d_enc_in2 = self._encoder_bwd(es2, dmulv2, param_grads=False)
+                # add the word-part gradient into d_out_emb rows (b, t < L)
+                ops.add3d(d_enc_in2.view(B, L, Din)[:, :, :E], d_out_emb.view(B, T, E)[:, :L])
+        enc_loss = ops.lincomb([(79.0, ce), (float(kld_coeff), kld)])  # cgn.py:1151
+        gen_loss = ops.lincomb([(1.0, enc_loss), (cfg.lambda_c if use_disc else 0.0, c_loss),
+                                (cfg.lambda_z if calc_z_loss else 0.0, z_loss)])  # cgn.py:1152
+        if not train:
+            return ce, kld, z_loss, c_loss, enc_loss, gen_loss
+        # ---- backward through softmax/CE + soft embedding, fused, in place over the logits ----------------------
+        rowdot = _new((NT,), dev)
+        if need_soft:
+            ops.rowdot(d_out_emb, out_emb, rowdot)
+            ops.gemm(d_out_emb, table.t(), logits,
+                     softmax_bwd=dict(logits=logits, lse=lse, rowdot=rowdot, target=tgt, inv_tau=inv_tau,
+                                      ce_scale=79.0 * inv_tau / NT))
+        else:
+            # CE only (initial VAE training, cgn.py:639-644): same epilogue with an empty product (K = 0)
+            ops.fill(rowdot, 0.0)
+            ops.gemm(dummy.view(NT, 1)[:, :0], table.t()[:0], logits,
+                     softmax_bwd=dict(logits=logits, lse=lse, rowdot=rowdot, target=tgt, inv_tau=inv_tau,
+                                      ce_scale=79.0 * inv_tau / NT))
+        dlogits = logits
+        ops.gemm(dlogits.t(), h1, G["generator.fc.weight"], N=Hg, K=NT, b_k=h1ax, b_n=LIN)
+        ops.colsum(dlogits, G["generator.fc.bias"])
+        dH1 = _new((NT, Hg), dev)
+        ops.gemm(dlogits, P["generator.fc.weight"], dH1)
+        # ---- generator LSTM backward ---------------------------------------------------------------------------
+        dc1 = _new((B, Hg), dev)
+        ops.fill(dc1, 0.0)
+        (dg1,) = engine.lstm_run_bwd([g1], [P["generator.rnn.weight_hh_l1"]], [(dH1, T * Hg, Hg)], [None], [dc1])
+        dg1_2 = engine.lstm_param_grads(g1, dg1, (h0, h0ax), G["generator.rnn.weight_ih_l1"],
+                                        G["generator.rnn.weight_hh_l1"], G["generator.rnn.bias_ih_l1"],
+                                        G["generator.rnn.bias_hh_l1"])
+        dH0 = _new((NT, Hg), dev)
+        ops.gemm(dg1_2, P["generator.rnn.weight_ih_l1"], dH0)
+        dc0 = _new((B, Hg), dev)
+        ops.fill(dc0, 0.0)
+        (dg0,) = engine.lstm_run_bwd([g0], [P["generator.rnn.weight_hh_l0"]], [(dH0, T * Hg, Hg)], [None], [dc0])
+        dWih0 = G["generator.rnn.weight_ih_l0"]
+        engine.lstm_param_grads(g0, dg0, (gen_emb, Axis(E, 0, 0)), dWih0[:, :E], G["generator.rnn.weight_hh_l0"],
+                                G["generator.rnn.bias_ih_l0"], G["generator.rnn.bias_hh_l0"])
+        dsum = _new((B, 4 * Hg), dev)
+        ops.sum_time(dg0, dsum)
+        ops.gemm(dsum.t(), zc, dWih0[:, E:])
+        dzc = _new((B, Z + C), dev)
+        ops.gemm(dsum, Wih0[:, E:], dzc)  # g = dzc[:, :Z] = d(79*CE + recon)/dz  (cgn.py:1099, 1142)
+        if capture is not None:
+            capture["g"] = dzc[:, :Z].clone()
+            capture["gen_grads"] = {n: g.clone() for n, g in self.arenas["gen"].grads.items()}
+        if not joint:
+            self._optim_step(opts[1])  # cgn.py:1143
+        # ---- encoder backward (cgn.py:1145-1149): kld_coef*KLD + z_out.backward(g) ---------------------------------
+        dmulv = _new((B, 2 * Z), dev)
+        ops.reparam_kld_bwd(mulv, eps, dzc, float(kld_coeff) / B, dmulv)
+        d_enc_in = self._encoder_bwd(es, dmulv, param_grads=True)
+        dtf = _new((N, S), dev)
+        ops.copy2d(d_enc_in[:, E:], dtf)
+        engine.tdnn_bwd(tsaved, tk, dtf, self._tdnn_kernels(G), G["embedding.char_embed.weight"])
+        if capture is not None:
+            capture["enc_grads"] = {n: g.clone() for n, g in self.arenas["enc"].grads.items()}
+        self._optim_step(opts[0])  # cgn.py:1149
+        if joint:
+            self._optim_step(opts[1])  # initial VAE training: one optimizer over everything (cgn.py:623,645)
+        return ce, kld, z_loss, c_loss, enc_loss, gen_loss

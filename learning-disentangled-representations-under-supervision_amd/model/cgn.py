@@ -1,0 +1,428 @@
+"""Controlled_Generation_Sentence — the CGN orchestrator (Hu et al. 2017) on MI355X.
+
+Same class name, constructor, sub-module names (hence state_dict keys) and step-closure API as the reference's
+model/cgn.py:24-1250. The step closures run the fused HIP step (hip/step.py); the module-level forward helpers
+(encode_for_z, train_rvae, discriminator_forward) run the same kernels through the modules' autograd Functions.
+
+Out of scope this round: the sleep-phase beam sampler (sample_from_generator,
+sample_generator_for_learning, cgn.py:747-1034).
+"""
+import numpy as np
+import torch as t
+import torch.nn as nn
+
+from ..hip import nn as hnn
+from ..hip.step import CGNStep
+from ..selfModules.embedding import Embedding
+from ..utils.functional import kld_coef, temp_coef
+from .discriminator_sentiment import Sentiment_CNN
+from .encoder import Encoder
+from .generator import Generator
+
+
+def _to_device_long(arr, use_cuda):
+    x = t.from_numpy(np.ascontiguousarray(arr)) if isinstance(arr, np.ndarray) else arr
+    x = x.long()
+    return x.cuda() if use_cuda else x
+
+
+class Controlled_Generation_Sentence(nn.Module):
+
+    def __init__(self, config, embedding_path):
+        super(Controlled_Generation_Sentence, self).__init__()
+
+        self.config = config
+        self.embedding = Embedding(self.config, embedding_path)
+        self.embedding_param_autograd = [1 if param.requires_grad else 0 for param in self.embedding.parameters()]
+
+        self.encoder = Encoder(self.config)
+        self.encoder_param_autograd = [1 if param.requires_grad else 0 for param in self.encoder.parameters()]
+
+        self.e2mu = hnn.Linear(self.config.encoder_rnn_size * 2, self.config.latent_variable_size)
+        self.e2logvar = hnn.Linear(self.config.encoder_rnn_size * 2, self.config.latent_variable_size)
+
+        self.generator = Generator(self.config)
+        self.generator_param_autograd = [1 if param.requires_grad else 0 for param in self.generator.parameters()]
+
+        self.sentiment_discriminator = Sentiment_CNN(self.config)
+        self.sentiment_discriminator_autograd = [1 if param.requires_grad else 0
+                                                 for param in self.sentiment_discriminator.parameters()]
+
+        # kld_coef variant: True reproduces the reference under its own interpreter (Python 2 floor division)
+        self.kld_py2_floor = True
+        # data parallelism hooks (parallel.py sets them): all-reduce callable over a flat gradient arena + world size
+        self._allreduce = None
+        self._world_size = 1
+        self._step_engine = None
+
+    # ------------------------------------------------------------------------------------------------------------
+    # fused-step engine (flat parameter arenas + HIP kernels), built lazily once the model sits on the GPU
+    # ------------------------------------------------------------------------------------------------------------
+    def step_engine(self):
+        eng = self._step_engine
+        if eng is None or not eng.valid():
+            eng = CGNStep(self, allreduce=self._allreduce, world_size=self._world_size)
+            self._step_engine = eng
+        return eng
+
+    def set_data_parallel(self, allreduce, world_size):
+        """allreduce(flat_fp32_grad_tensor) must sum the tensor in place over all ranks (e.g. RCCL all_reduce)."""
+        self._allreduce, self._world_size = allreduce, int(world_size)
+        self._step_engine = None
+
+    def compute_mahalabonis(self, mu1, mu2, std1, std2):
+        """cgn.py:47-57 (diagnostic helper; the training step uses the fused kernel cgn_mahalanobis_f32)."""
+        std = (std1 + std2) / 2
+        delta_mu = mu1 - mu2
+        return t.sqrt(t.sum(delta_mu * t.reciprocal(std) * delta_mu, 1))
+
+    def encode_for_z(self, encoder_input, batch_size, use_cuda, eps=None):
+        """cgn.py:83-103. `eps` optionally replaces the t.randn draw of :96. Returns (z, std, logvar, mu)."""
+        context, h_0, c_0 = self.encoder(encoder_input, None)
+        mu = self.e2mu(context)
+        logvar = self.e2logvar(context)
+        if eps is None:
+            eps = t.randn([batch_size, self.config.latent_variable_size])
+        eps = eps.to(mu.device)
+        z, std = _ReparamFn.apply(mu, logvar, eps)
+        return z, std, logvar, mu
+
+    def train_rvae(self, drop_prob, encoder_word_input=None, encoder_char_input=None, generator_word_input=None,
+                   eps=None, c=None):
+        """cgn.py:105-132: VAE forward with a random code c ~ Bernoulli(0.5). Returns (out, final_state, kld, mu, std, z)."""
+        use_cuda = self.embedding.word_embed.weight.is_cuda
+        [batch_size, _] = encoder_word_input.size()
+        encoder_input = self.embedding(encoder_word_input, encoder_char_input)
+        z, std, logvar, mu = self.encode_for_z(encoder_input, batch_size, use_cuda, eps)
+        if c is None:
+            c = t.bernoulli(t.ones(batch_size, self.config.c_size) * 0.5)
+        c = c.to(z.device).view(batch_size, -1)
+        input_code = _ZCFn.apply(z, c)
+        kld = _KldFn.apply(mu, logvar)
+        generator_input = self.embedding.word_embed(generator_word_input)
+        out, final_state = self.generator(generator_input, input_code, drop_prob, None)
+        return out, final_state, kld, mu, std, z
+
+    def discriminator_forward(self, input_data, batch_size, use_cuda, uniform=None):
+        """cgn.py:134-172: c ~ Bernoulli(softmax(D(word_embed(encoder_word_input)))[:, 1]); returns c [B] (float).
+        `uniform` optionally supplies the U[0,1) draw behind the Bernoulli sample."""
+        self.sentiment_discriminator.eval()
+        encoder_word_input = _to_device_long(input_data[0], use_cuda)
+        eng = self.step_engine()
+        if uniform is None:
+            uniform = t.rand(encoder_word_input.size(0))
+        c, _ = eng.infer_c(encoder_word_input.contiguous(), uniform.to(eng.dev, t.float32).contiguous())
+        return c
+
+    # ------------------------------------------------------------------------------------------------------------
+    # discriminator step closures (cgn.py:174-343)
+    # ------------------------------------------------------------------------------------------------------------
+    def _disc_batches(self, data_handler, batch_X, batch_Y, generated_samples, generated_c, use_cuda):
+        dev_long = lambda x: _to_device_long(x, use_cuda).contiguous()  # noqa: E731
+        X = dev_long(data_handler.create_sentiment_batch(batch_X))
+        Y = dev_long(np.array(batch_Y))
+        GX = dev_long(data_handler.create_sentiment_batch(generated_samples))
+        GY = generated_c.view(-1).long()
+        GY = (GY.cuda() if use_cuda else GY).contiguous()
+        return X, Y, GX, GY
+
+    def _disc_masks(self, B_l, B_g, dev):
+        p = self.config.sentiment_dropout
+        if not self.sentiment_discriminator.training or not p:
+            return None, None
+        F_ = len(self.config.sentiment_kernel_size) * self.config.sentiment_kernel_num
+        keep = 1.0 - p
+        return ((t.rand(B_l, F_, device=dev) < keep).float() / keep, (t.rand(B_g, F_, device=dev) < keep).float() / keep)
+
+    def discriminator_sentiment_valid(self, data_handler, use_cuda, return_accuracy=False):
+        """cgn.py:174-240."""
+
+        def valid(batch_index, generated_samples, generated_c):
+            self.sentiment_discriminator.eval()
+            batch_X, batch_Y = data_handler.get_sentiment_dev_batch(batch_index)
+            X, Y, GX, GY = self._disc_batches(data_handler, batch_X, batch_Y, generated_samples, generated_c, use_cuda)
+            eng = self.step_engine()
+            _, ce_l, _, ce_g, _ = eng.disc_train(None, X, Y, GX, GY, train=False)
+            if not return_accuracy:
+                return ce_l, ce_g
+            c_l, p_l = eng.infer_c(X, t.full((X.size(0),), 0.5, device=eng.dev))   # c = [p1 > 0.5] = argmax
+            c_g, p_g = eng.infer_c(GX, t.full((GX.size(0),), 0.5, device=eng.dev))
+            correct = (c_l.long() == Y).sum()
+            generated_correct = (c_g.long() == GY).sum()
+            return ce_l, ce_g, correct, generated_correct
+
+        return valid
+
+    def discriminator_sentiment_trainer(self, data_handler, use_cuda):
+        """cgn.py:242-343: returns train(generated_samples, generated_c, batch_index) -> 5-tuple
+        (total_loss, batch_train_ce_loss, generated_loss, generated_loss_ce, emperical_shannon_entropy).
+        Extra keyword arguments mask_labelled / mask_generated pin the dropout masks (parity tests)."""
+        optimizer = [None]
+
+        def train(generated_samples, generated_c, batch_index, mask_labelled=None, mask_generated=None, capture=None):
+            batch_X, batch_Y = data_handler.get_sentiment_train_batch(batch_index)
+            X, Y, GX, GY = self._disc_batches(data_handler, batch_X, batch_Y, generated_samples, generated_c, use_cuda)
+            eng = self.step_engine()
+            if optimizer[0] is None or optimizer[0].arena is not eng.arenas["disc"]:
+                optimizer[0] = eng.new_optimizer("disc")
+            if mask_labelled is None and mask_generated is None:
+                mask_labelled, mask_generated = self._disc_masks(X.size(0), GX.size(0), eng.dev)
+            return eng.disc_train(optimizer[0], X, Y, GX, GY, mask_labelled, mask_generated, capture=capture)
+
+        return train
+
+    # ------------------------------------------------------------------------------------------------------------
+    # mode switches (cgn.py:346-395, 688-745) — kept for API compatibility; the fused step decides what to update from
+    # the closure being called, exactly as the reference's optimizers do from their parameter lists
+    # ------------------------------------------------------------------------------------------------------------
+    def prep_disc_validation(self):
+        self.discriminator_mode(train_mode=False)
+        self.encoder_mode(train_mode=False)
+        self.generator_mode(train_mode=False)
+        self.sentiment_discriminator.eval()
+        self.encoder.eval()
+        self.generator.eval()
+
+    def prep_disc_training(self):
+        self.discriminator_mode(train_mode=True)
+        self.encoder_mode(train_mode=False)
+        self.generator_mode(train_mode=False)
+        self.sentiment_discriminator.train()
+        self.encoder.eval()
+        self.generator.eval()
+
+    def prep_enc_gen_validation(self):
+        self.encoder_mode(train_mode=False)
+        self.generator_mode(train_mode=False)
+        self.discriminator_mode(train_mode=False)
+        self.encoder.eval()
+        self.generator.eval()
+        self.sentiment_discriminator.eval()
+
+    def prep_enc_gen_training(self):
+        self.discriminator_mode(train_mode=False)
+        self.sentiment_discriminator.eval()
+        self.encoder_mode(train_mode=True)
+        self.generator_mode(train_mode=True)
+        self.encoder.train()
+        self.generator.train()
+
+    def encoder_params(self):
+        enc_params = [p for p in self.encoder.parameters() if p.requires_grad]
+        enc_params.extend([p for p in self.embedding.parameters() if p.requires_grad])
+        enc_params.extend([p for p in self.e2mu.parameters() if p.requires_grad])
+        enc_params.extend([p for p in self.e2logvar.parameters() if p.requires_grad])
+        return enc_params
+
+    def generator_params(self):
+        return [p for p in self.generator.parameters() if p.requires_grad]
+
+    def sentiment_discriminator_parameters(self):
+        return [p for p in self.sentiment_discriminator.parameters() if p.requires_grad]
+
+    def learnable_parameters(self):
+        return [p for p in self.parameters() if p.requires_grad]
+
+    def encoder_mode(self, train_mode=False):
+        for i, param in enumerate(self.encoder.parameters()):
+            param.requires_grad = bool(train_mode and self.encoder_param_autograd[i])
+        for i, param in enumerate(self.embedding.parameters()):
+            param.requires_grad = bool(train_mode and self.embedding_param_autograd[i])
+        for param in list(self.e2mu.parameters()) + list(self.e2logvar.parameters()):
+            param.requires_grad = bool(train_mode)
+
+    def discriminator_mode(self, train_mode=True):
+        for i, param in enumerate(self.sentiment_discriminator.parameters()):
+            param.requires_grad = bool(train_mode and self.sentiment_discriminator_autograd[i])
+
+    def generator_mode(self, train_mode=True):
+        for i, param in enumerate(self.generator.parameters()):
+            param.requires_grad = bool(train_mode and self.generator_param_autograd[i])
+
+    # ------------------------------------------------------------------------------------------------------------
+    # initial VAE pre-training (cgn.py:621-674): one optimizer over every learnable parameter, no detach, no D
+    # ------------------------------------------------------------------------------------------------------------
+    def _rvae_step(self, opts, input, i, dropout, train, eps=None, c=None):
+        eng = self.step_engine()
+        use_cuda = True
+        enc_word, enc_char, dec_word, _, target = [None if v is None else _to_device_long(v, use_cuda).contiguous()
+                                                   for v in input]
+        B = enc_word.size(0)
+        if eps is None:
+            eps = t.randn([B, self.config.latent_variable_size])
+        if c is None:
+            c = t.bernoulli(t.ones(B, self.config.c_size) * 0.5)  # cgn.py:119-120
+        mask = _gen_mask(self.generator, dec_word, dropout, self.config.word_embed_size, eng.dev) if train else None
+        kc = kld_coef(i, py2_floor=self.kld_py2_floor)
+        ce, kld, _, _, enc_loss, _ = eng.enc_gen_train(
+            opts, enc_word, enc_char, dec_word, target, c.to(eng.dev, t.float32).contiguous(),
+            eps.to(eng.dev, t.float32).contiguous(), kc, 1.0, gen_drop_mask=mask, calc_z_loss=False, train=train,
+            use_disc=False, joint=True)
+        return ce, kld, kc, enc_loss  # loss = 79*ce + kld_coef*kld (cgn.py:641)
+
+    def initial_rvae_trainer(self, data_handler):
+        opts = [None]
+
+        def train(i, batch_size, use_cuda, dropout, start_index, eps=None, c=None):
+            input = data_handler.gen_batch_loader.next_batch(batch_size, 'train', start_index)
+            eng = self.step_engine()
+            if opts[0] is None or opts[0][0].arena is not eng.arenas["enc"]:
+                opts[0] = (eng.new_optimizer("enc"), eng.new_optimizer("gen"))
+            return self._rvae_step(opts[0], input, i, dropout, True, eps, c)
+
+        return train
+
+    def initial_rvae_valid(self, data_handler):
+        def valid(i, batch_size, use_cuda, dropout, start_index, eps=None, c=None):
+            input = data_handler.gen_batch_loader.next_batch(batch_size, 'valid', start_index)
+            return self._rvae_step(None, input, i, 0, False, eps, c)
+
+        return valid
+
+    # ------------------------------------------------------------------------------------------------------------
+    # encoder/generator step closures (cgn.py:1043-1250)
+    # ------------------------------------------------------------------------------------------------------------
+    def _enc_gen(self, opts, input, use_cuda, dropout, c_target, global_step, calc_z_loss, train, eps, gen_drop_mask,
+                 capture):
+        if not use_cuda:
+            raise RuntimeError("the CGN step runs on the MI355X only (use_cuda must be True); there is no CPU path")
+        enc_word, enc_char, dec_word, _, target = [None if v is None else _to_device_long(v, use_cuda).contiguous()
+                                                   for v in input]
+        eng = self.step_engine()
+        B = enc_word.size(0)
+        if eps is None:
+            eps = t.randn([B, self.config.latent_variable_size])  # cgn.py:96 (CPU draw, then moved)
+        if train and gen_drop_mask is None:
+            gen_drop_mask = _gen_mask(self.generator, dec_word, dropout, self.config.word_embed_size, eng.dev)
+        kld_coeff = kld_coef(global_step, py2_floor=self.kld_py2_floor)  # cgn.py:1074
+        logit_temperature = temp_coef(global_step)  # cgn.py:1086
+        c = c_target.to(eng.dev, t.float32).contiguous()
+        ce, kld, z_loss, c_loss, enc_loss, gen_loss = eng.enc_gen_train(
+            opts, enc_word, enc_char, dec_word, target, c, eps.to(eng.dev, t.float32).contiguous(), kld_coeff,
+            logit_temperature, gen_drop_mask=gen_drop_mask, calc_z_loss=calc_z_loss, capture=capture, train=train)
+        return ce, kld, z_loss, c_loss, kld_coeff, logit_temperature, enc_loss, gen_loss
+
+    def train_encoder_generator(self, summary_writer=None):
+        """cgn.py:1043-1156. Returns train(input, batch_size, use_cuda, dropout, c_target, global_step,
+        calc_z_loss=True) -> (cross_entropy, kld, z_loss, c_loss, kld_coeff, logit_temperature, total_encoder_loss,
+        total_generator_loss). Keyword-only extras: eps, gen_drop_mask (explicit random draws), capture (dict that
+        receives g and the gradients seen by each optimizer)."""
+        opts = [None]
+
+        def train(input, batch_size, use_cuda, dropout, c_target, global_step, calc_z_loss=True, *, eps=None,
+                  gen_drop_mask=None, capture=None):
+            eng = self.step_engine()
+            if opts[0] is None or opts[0][0].arena is not eng.arenas["enc"]:
+                opts[0] = (eng.new_optimizer("enc"), eng.new_optimizer("gen"))  # cgn.py:1046-1047
+            return self._enc_gen(opts[0], input, use_cuda, dropout, c_target, global_step, calc_z_loss, True, eps,
+                                 gen_drop_mask, capture)
+
+        return train
+
+    def valid_encoder_generator(self):
+        """cgn.py:1159-1250 (forward only, dropout 0)."""
+
+        def valid(input, batch_size, use_cuda, c_target, global_step, calc_z_loss=True, *, eps=None):
+            return self._enc_gen(None, input, use_cuda, 0.0, c_target, global_step, calc_z_loss, False, eps, None, None)
+
+        return valid
+
+    # ------------------------------------------------------------------------------------------------------------
+    def sample_from_generator(self, *args, **kwargs):
+        raise NotImplementedError("sleep-phase beam sampler (cgn.py:747-921) is the next row after the training step "
+                                  "(SURVEY.md §8f rank 1); not built in this round")
+
+    def sample_generator_for_learning(self, *args, **kwargs):
+        raise NotImplementedError("sleep-phase sampler (cgn.py:993-1034): SURVEY.md §8f rank 1; not built this round")
+
+
+def _gen_mask(generator, dec_word, dropout, E, dev):
+    """Word-dropout mask for F.dropout(generator_input, drop_prob) (generator.py:52); see generator._dropout_mask."""
+    if isinstance(dropout, t.Tensor):
+        return dropout.to(dev, t.float32).contiguous()
+    if generator.legacy_dropout_noop or not dropout:
+        return None
+    keep = 1.0 - float(dropout)
+    B, T = dec_word.shape
+    return (t.rand(B, T, E, device=dev) < keep).float() / keep
+
+
+class _ReparamFn(t.autograd.Function):
+    """z = eps * exp(0.5 * logvar) + mu ; std = exp(0.5 * logvar)   (cgn.py:94-101)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        from ..hip import ops
+        B, Z = mu.shape
+        mulv = hnn.new((B, 2 * Z), mu.device)
+        ops.copy2d(hnn.f32c(mu), mulv[:, :Z])
+        ops.copy2d(hnn.f32c(logvar), mulv[:, Z:])
+        zc, std, kld = hnn.new((B, Z), mu.device), hnn.new((B, Z), mu.device), hnn.new((1,), mu.device)
+        e = hnn.f32c(eps.to(t.float32))
+        ops.reparam_kld_fwd(mulv, e, None, zc, std, kld)
+        ctx.save_for_backward(mulv, e)
+        return zc, std
+
+    @staticmethod
+    def backward(ctx, dz, dstd):
+        from ..hip import ops
+        mulv, e = ctx.saved_tensors
+        B, Z2 = mulv.shape
+        Z = Z2 // 2
+        d = hnn.new((B, Z2), mulv.device)
+        ops.reparam_kld_bwd(mulv, e, hnn.f32c(dz), 0.0, d)
+        dmu, dlv = hnn.f32c(d[:, :Z]), hnn.f32c(d[:, Z:])
+        if dstd is not None:
+            # d std / d logvar = 0.5 * std ; fold through the same kernel with eps := 1
+            ones = hnn.new((B, Z), mulv.device)
+            ops.fill(ones, 1.0)
+            d2 = hnn.new((B, Z2), mulv.device)
+            ops.reparam_kld_bwd(mulv, ones, hnn.f32c(dstd), 0.0, d2)
+            ops.copy2d(d2[:, Z:], dlv, beta=1.0)
+        return dmu, dlv, None
+
+
+class _KldFn(t.autograd.Function):
+    """kld = mean_b(-0.5 * sum_z(logvar - mu^2 - exp(logvar) + 1))   (cgn.py:127, :1076)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar):
+        from ..hip import ops
+        B, Z = mu.shape
+        mulv = hnn.new((B, 2 * Z), mu.device)
+        ops.copy2d(hnn.f32c(mu), mulv[:, :Z])
+        ops.copy2d(hnn.f32c(logvar), mulv[:, Z:])
+        eps = hnn.new((B, Z), mu.device)
+        ops.fill(eps, 0.0)
+        zc, std, kld = hnn.new((B, Z), mu.device), hnn.new((B, Z), mu.device), hnn.new((1,), mu.device)
+        ops.reparam_kld_fwd(mulv, eps, None, zc, std, kld)
+        ctx.save_for_backward(mulv, eps)
+        return kld.view(())
+
+    @staticmethod
+    def backward(ctx, dk):
+        from ..hip import ops
+        mulv, eps = ctx.saved_tensors
+        B, Z2 = mulv.shape
+        Z = Z2 // 2
+        d = hnn.new((B, Z2), mulv.device)
+        ops.reparam_kld_bwd(mulv, eps, None, float(dk) / B, d)
+        return hnn.f32c(d[:, :Z]), hnn.f32c(d[:, Z:])
+
+
+class _ZCFn(t.autograd.Function):
+    """t.cat((z, c), 1)   (cgn.py:125, :1080)."""
+
+    @staticmethod
+    def forward(ctx, z, c):
+        from ..hip import ops
+        B, Z = z.shape
+        out = hnn.new((B, Z + c.shape[1]), z.device)
+        ops.copy2d(hnn.f32c(z), out[:, :Z])
+        ops.copy2d(hnn.f32c(c.to(t.float32)), out[:, Z:])
+        ctx.Z = Z
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        return hnn.f32c(hnn.f32c(d)[:, :ctx.Z]), None

@@ -1,0 +1,70 @@
+"""Synthetic data with the layout of the reference's loaders (utils/batch_loader.py:271-316, utils/data_handler.py:69-102)
+for tests and benchmarks: fixed-length sentences, encoder input reversed, dec = [go]+s, target = s+[end], the three
+special tokens are the last vocabulary indices (batch_loader.py:81-85). The real text pipeline (pickled corpora,
+vocabulary building) is CPU data preparation outside the hot path."""
+import numpy as np
+import torch
+
+
+def word_embeddings(config, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    return ((torch.rand(config.word_vocab_size, config.word_embed_size, generator=g) * 2 - 1) * 0.25).numpy()
+
+
+class _GenBatchLoader:
+    def __init__(self, config, L, train_lines, seed):
+        self.config, self.L, self.train_lines, self.seed = config, L, train_lines, seed
+
+    def next_batch(self, batch_size, target_str, start_index):
+        """Five arrays like batch_loader.py:271-316: [enc_word, enc_char, dec_word, dec_char, target] (int64)."""
+        cfg, L = self.config, self.L
+        V = cfg.word_vocab_size
+        rng = np.random.RandomState((self.seed + 7919 * start_index + (0 if target_str == 'train' else 1)) % (2 ** 31))
+        s = rng.randint(0, V - 3, size=(batch_size, L)).astype(np.int64)
+        chars = rng.randint(0, cfg.char_vocab_size, size=(batch_size, L, cfg.max_word_len)).astype(np.int64)
+        go, end = V - 2, V - 1
+        enc_word = np.ascontiguousarray(s[:, ::-1])
+        enc_char = np.ascontiguousarray(chars[:, ::-1])
+        dec_word = np.concatenate([np.full((batch_size, 1), go, np.int64), s], 1)
+        dec_char = np.zeros((batch_size, L + 1, cfg.max_word_len), np.int64)
+        target = np.concatenate([s, np.full((batch_size, 1), end, np.int64)], 1)
+        return [enc_word, enc_char, dec_word, dec_char, target]
+
+
+class SyntheticDataHandler:
+    """Duck-types the parts of utils/data_handler.py DataHandler that the step closures touch."""
+
+    def __init__(self, config, batch_size, seq_len, num_batches=8, seed=1234):
+        self.config, self.batch_size, self.L, self.seed = config, batch_size, seq_len, seed
+        self.num_train_sentiment_batches = num_batches
+        self.num_dev_sentiment_batches = num_batches
+        self.gen_batch_loader = _GenBatchLoader(config, seq_len, batch_size * num_batches, seed)
+
+    def _labelled(self, batch_index, salt):
+        rng = np.random.RandomState((self.seed + 104729 * batch_index + salt) % (2 ** 31))
+        X = rng.randint(0, self.config.word_vocab_size - 3, size=(self.batch_size, self.L)).tolist()
+        Y = rng.randint(0, 2, size=(self.batch_size,)).tolist()
+        return X, Y
+
+    def get_sentiment_train_batch(self, batch_index):
+        return self._labelled(batch_index, 11)
+
+    def get_sentiment_dev_batch(self, batch_index):
+        return self._labelled(batch_index, 13)
+
+    def create_sentiment_batch(self, sentences):
+        """data_handler.py:87-102: pad to the in-batch maximum with the pad token (third-last vocab index)."""
+        if isinstance(sentences, torch.Tensor):
+            return sentences.long()
+        pad = self.config.word_vocab_size - 3
+        m = max(len(s) for s in sentences)
+        out = np.full((len(sentences), m), pad, np.int64)
+        for i, s in enumerate(sentences):
+            out[i, :len(s)] = s
+        return torch.from_numpy(out)
+
+    def synthetic_generated_samples(self, n, step=0):
+        rng = np.random.RandomState((self.seed + 31 * step + 17) % (2 ** 31))
+        X = rng.randint(0, self.config.word_vocab_size - 3, size=(n, self.L)).tolist()
+        c = torch.from_numpy(rng.randint(0, 2, size=(n, 1)).astype(np.float32))
+        return X, c

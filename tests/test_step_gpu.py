@@ -1,0 +1,166 @@
+"""GPU parity of the fused HIP wake-sleep step against the CPU oracle (oracle/cgn_oracle.py, fp64) on identical
+weights, inputs and random draws. Bar (BASELINE.json north_star): fp32 relative error <= 1e-4 for every loss and every
+gradient tensor (relative Frobenius norm); post-Adam parameter updates are compared the same way.
+The drop-in closures of model/cgn.py (reference API, numpy batches) are what is called."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cgn_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _pkg():
+    import ldrs_amd  # noqa: F401
+    from ldrs_amd.model.cgn import Controlled_Generation_Sentence
+    from ldrs_amd.utils.config import Config
+    return Controlled_Generation_Sentence, Config
+
+
+CFGS = {
+    "tiny": dict(max_word_len=7, max_seq_len=5, word_vocab_size=50, char_vocab_size=20, word_embed_size=12,
+                 kernels=((1, 3), (2, 5), (3, 4)), encoder_rnn_size=16, latent_variable_size=6, decoder_rnn_size=20,
+                 sentiment_kernel_size=(3, 4, 5), sentiment_kernel_num=6),
+    # odd sizes: Din = 33+31 = 64 -> no; E=33 makes every row stride unaligned; H not a multiple of 16
+    "odd": dict(max_word_len=8, max_seq_len=9, word_vocab_size=203, char_vocab_size=31, word_embed_size=33,
+                kernels=((1, 5), (2, 7), (3, 6), (6, 13)), encoder_rnn_size=36, latent_variable_size=10,
+                decoder_rnn_size=44, sentiment_kernel_size=(3, 4, 5), sentiment_kernel_num=9),
+    # reference-like proportions at reduced size (default TDNN kernels, E=300)
+    "mid": dict(max_word_len=12, max_seq_len=10, word_vocab_size=1200, char_vocab_size=64, encoder_rnn_size=64,
+                latent_variable_size=32, decoder_rnn_size=96, sentiment_kernel_num=20),
+}
+
+
+def rel(a, ref):
+    a = a.detach().double().cpu().reshape(-1)
+    ref = ref.detach().double().cpu().reshape(-1)
+    return (a - ref).norm().item() / max(ref.norm().item(), 1e-300)
+
+
+class Handler:
+    """Feeds the closures the oracle's synthetic batch through the reference's data_handler interface."""
+
+    def __init__(self, data, cfg):
+        self.d, self.cfg = data, cfg
+
+    def get_sentiment_train_batch(self, i):
+        return self.d["x_labelled"].tolist(), self.d["y_labelled"].tolist()
+
+    get_sentiment_dev_batch = get_sentiment_train_batch
+
+    def create_sentiment_batch(self, s):
+        return torch.tensor(s, dtype=torch.int64)
+
+
+def build(name, dev, seed=0):
+    CGN, Config = _pkg()
+    kw = CFGS[name]
+    ocfg = O.OracleConfig(**kw)
+    torch.manual_seed(seed)
+    emb = O.synthetic_word_embed(ocfg)
+    oracle = O.CGN(ocfg, emb).double()
+    ckw = dict(kw)
+    pos = [ckw.pop(k) for k in ("max_word_len", "max_seq_len", "word_vocab_size", "char_vocab_size")]
+    cfg = Config(*pos, 5e-5, 7.9, 0.1, 0.1, 1.0, **ckw)
+    model = CGN(cfg, emb)
+    model.load_state_dict({k: v.float() for k, v in oracle.state_dict().items()})
+    model = model.cuda()
+    return ocfg, oracle, cfg, model
+
+
+@pytest.mark.parametrize("name,B,calc_z", [("tiny", 4, False), ("tiny", 5, True), ("odd", 7, True), ("mid", 16, False),
+                                           ("mid", 8, True)])
+def test_wake_sleep_step_matches_oracle(dev, name, B, calc_z):
+    ocfg, oracle, cfg, model = build(name, dev)
+    L = ocfg.max_seq_len - 1
+    F_ = len(ocfg.sentiment_kernel_size) * ocfg.sentiment_kernel_num
+    opts = O.make_optimizers(oracle)
+    handler = None
+    disc_train = enc_gen_train = None
+    for step in range(3):  # three steps: Adam moments and the changed weights are exercised too
+        data = O.synthetic_batch(ocfg, B, L, seed=100 + step)
+        g = torch.Generator().manual_seed(7 + step)
+        masks = dict(labelled=(torch.rand(B, F_, generator=g) < 0.7).double() / 0.7,
+                     generated=(torch.rand(B, F_, generator=g) < 0.7).double() / 0.7,
+                     gen_drop=(torch.rand(B, L + 1, ocfg.word_embed_size, generator=g) < 0.7).double() / 0.7)
+        ddata = {k: (v.double() if v.is_floating_point() else v) for k, v in data.items()}
+        gstep = 5000 + 1000 * step
+        cap_o = {}
+        before = {n: p.detach().clone() for n, p in oracle.named_parameters()}
+        d_o, c_o, eg_o = O.wake_sleep_step(oracle, opts, ddata, gstep, calc_z_loss=calc_z, masks=masks, capture=cap_o)
+
+        # ---- HIP path through the reference-API closures ---------------------------------------------------------
+        handler = Handler(data, cfg)
+        if disc_train is None:
+            disc_train = model.discriminator_sentiment_trainer(handler, True)
+            enc_gen_train = model.train_encoder_generator()
+        else:
+            disc_train.__closure__  # same closures, new data through the handler object below
+        # closures captured the first handler; point it at this step's data
+        if step > 0:
+            first_handler.d = data
+        else:
+            first_handler = handler
+        cap = {}
+        model.prep_disc_training()
+        d_h = disc_train(data["x_generated"].tolist(), data["c_generated"].float().view(-1, 1), 0,
+                         mask_labelled=masks["labelled"].float().to(dev), mask_generated=masks["generated"].float().to(dev),
+                         capture=cap)
+        batch = [data["enc_word"].numpy(), data["enc_char"].numpy(), data["dec_word"].numpy(), None,
+                 data["target"].numpy()]
+        model.discriminator_mode(train_mode=False)
+        c_h = model.discriminator_forward(batch, B, True, uniform=data["c_uniform"])
+        assert torch.equal(c_h.cpu().double(), c_o), "inferred c differs"
+        model.prep_enc_gen_training()
+        eg_h = enc_gen_train(batch, B, True, masks["gen_drop"].float().to(dev), c_h, gstep, calc_z_loss=calc_z,
+                             eps=data["eps"], capture=cap)
+
+        for a, b, nm in zip(d_h, d_o, ("total", "ce_l", "gen_loss", "ce_g", "entropy")):
+            assert rel(a, b) < TOL, ("disc loss", nm, step)
+        names = ("ce", "kld", "z_loss", "c_loss", "kld_coef", "temp", "enc_loss", "gen_loss")
+        for a, b, nm in zip(eg_h, eg_o, names):
+            a = a if isinstance(a, torch.Tensor) else torch.tensor(float(a))
+            b = b if isinstance(b, torch.Tensor) else torch.tensor(float(b))
+            if nm == "z_loss" and not calc_z:
+                assert float(a) == 0.0
+                continue
+            assert rel(a, b) < TOL, ("enc-gen loss", nm, step, float(a), float(b))
+        assert rel(cap["g"], cap_o["g"]) < TOL, ("g", step)
+        for key, okey, prefix in (("disc_grads", "disc_grads", "sentiment_discriminator."),
+                                  ("gen_grads", "gen_grads", "generator."), ("enc_grads", "enc_grads", "")):
+            for n, gref in cap_o[okey].items():
+                full = n if n.startswith(prefix) else prefix + n
+                assert rel(cap[key][full], gref) < TOL, (key, full, step, rel(cap[key][full], gref))
+        after_o = dict(oracle.named_parameters())
+        after_h = dict(model.named_parameters())
+        for n, p0 in before.items():
+            upd_o = after_o[n].detach() - p0
+            upd_h = after_h[n].detach().cpu().double() - p0
+            if upd_o.abs().max() == 0:
+                assert upd_h.abs().max() < 1e-7, n  # frozen (word embedding)
+            else:
+                assert rel(upd_h, upd_o) < 2e-3, ("update", n, step, rel(upd_h, upd_o))
+                assert rel(after_h[n], after_o[n]) < 1e-6, ("weights", n, step)
+
+
+def test_validation_closure_is_forward_only(dev):
+    ocfg, oracle, cfg, model = build("tiny", dev)
+    B, L = 4, ocfg.max_seq_len - 1
+    data = O.synthetic_batch(ocfg, B, L, seed=5)
+    batch = [data["enc_word"].numpy(), data["enc_char"].numpy(), data["dec_word"].numpy(), None, data["target"].numpy()]
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    valid = model.valid_encoder_generator()
+    c = torch.tensor([0., 1., 1., 0.])
+    out = valid(batch, B, True, c, 5000, calc_z_loss=True, eps=data["eps"])
+    for n, p in model.named_parameters():
+        assert torch.equal(p.detach(), before[n]), n
+    # against the oracle's training closure losses (same forward)
+    O.prep_enc_gen_training(oracle)
+    opts = O.make_optimizers(oracle)
+    ref = O.enc_gen_train_step(oracle, opts[1], opts[2], [data["enc_word"], data["enc_char"], data["dec_word"], None,
+                                                          data["target"]], c.double(), data["eps"].double(), 5000,
+                               calc_z_loss=True, eps_recon=data["eps_recon"].double())
+    for i in (0, 1, 2, 3, 6, 7):
+        assert rel(out[i], ref[i]) < TOL, i
