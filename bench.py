@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Benchmark of the CGN wake-sleep training step on MI355X (BASELINE.json metric: sentences/sec).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = one full wake-sleep step over one batch of synthetic sentences per GPU: discriminator step
+(model/cgn.py:269-341 of the reference) + c inference (:134-172) + encoder/generator step (:1049-1154, calc_z_loss=False
+as train_functions.py:90 passes) + the three Adam updates. The beam sampler is excluded; the "generated" batch is
+synthetic. Workload = BASELINE.json configs[1]: vocab 20k, seq len 20, batch 64/GPU, emb 300,
+hidden 512, z 64, fp32. Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0) with the throughput, a `roofline` object for the dominant kernel (the NT 128x128 fp32
+MFMA GEMM; per-launch times from HIP events on the launch stream inside the timed region) and, at N=1, a
+`cpu_baseline` object (the CPU oracle restatement of the same step on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG2 = dict(max_word_len=12, max_seq_len=20, word_vocab_size=20000, char_vocab_size=64, word_embed_size=300,
+            encoder_rnn_size=512, latent_variable_size=64, decoder_rnn_size=512, decoder_num_layers=2,
+            sentiment_kernel_size=(3, 4, 5), sentiment_kernel_num=100)
+BATCH, SEQ = 64, 20
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def make_config(Config):
+    kw = dict(CFG2)
+    pos = [kw.pop(k) for k in ("max_word_len", "max_seq_len", "word_vocab_size", "char_vocab_size")]
+    return Config(*pos, 5e-5, 7.9, 0.1, 0.1, 1.0, **kw)
+
+
+def device_data(O, ocfg, B, L, seed, dev, drop_p=0.3):
+    d = O.synthetic_batch(ocfg, B, L, seed=seed)
+    F_ = len(ocfg.sentiment_kernel_size) * ocfg.sentiment_kernel_num
+    g = torch.Generator().manual_seed(seed + 1)
+    keep = 1.0 - drop_p
+    d["mask_labelled"] = (torch.rand(B, F_, generator=g) < keep).float() / keep
+    d["mask_generated"] = (torch.rand(B, F_, generator=g) < keep).float() / keep
+    return {k: v.to(dev).contiguous() for k, v in d.items()}, d
+
+
+def cpu_baseline(O, ocfg, host_data, global_step, budget_s=25.0):
+    """The oracle restatement of the same step on the host cores ("port"), bounded to ~budget_s of CPU work."""
+    torch.manual_seed(1234)
+    model = O.CGN(ocfg, O.synthetic_word_embed(ocfg))
+    opts = O.make_optimizers(model)
+    data = {k: v for k, v in host_data.items() if not k.startswith("mask_")}
+    masks = dict(labelled=host_data["mask_labelled"], generated=host_data["mask_generated"])
+    B = data["enc_word"].shape[0]
+    t0 = time.perf_counter()
+    O.wake_sleep_step(model, opts, data, global_step, calc_z_loss=False, masks=masks)  # warm-up (allocator, threads)
+    warm = time.perf_counter() - t0
+    times = []
+    while len(times) < 10 and (sum(times) + warm) < budget_s:
+        t0 = time.perf_counter()
+        O.wake_sleep_step(model, opts, data, global_step, calc_z_loss=False, masks=masks)
+        times.append(time.perf_counter() - t0)
+    if not times:
+        times = [warm]
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": B / med, "unit": "sentences/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d full wake-sleep steps of the same cfg2 batch (B=%d) after 1 warm-up, median; CPU fp32 "
+                      "torch restatement oracle/cgn_oracle.py" % (len(times), B)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--z-loss", action="store_true", help="include the z-reconstruction pass (calc_z_loss=True)")
+    args = ap.parse_args()
+
+    import ldrs_amd  # noqa: F401
+    from ldrs_amd import parallel
+    from ldrs_amd.hip import ops
+    from ldrs_amd.model.cgn import Controlled_Generation_Sentence
+    from ldrs_amd.utils.config import Config
+    from ldrs_amd.utils.functional import kld_coef, temp_coef
+    from oracle import cgn_oracle as O  # synthetic inputs + the cpu_baseline leg only
+
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the CGN hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    cfg = make_config(Config)
+    ocfg = O.OracleConfig(**CFG2)
+    torch.manual_seed(1234)  # identical replicas on every rank
+    model = Controlled_Generation_Sentence(cfg, O.synthetic_word_embed(ocfg)).cuda()
+    if world > 1:
+        parallel.attach(model)
+    eng = model.step_engine()
+    opts = dict(disc=eng.new_optimizer("disc"), enc=eng.new_optimizer("enc"), gen=eng.new_optimizer("gen"))
+    data, host_data = device_data(O, ocfg, BATCH, SEQ, 1234 + rank, dev)
+    global_step = 5000
+    kc, tau = kld_coef(global_step), temp_coef(global_step)
+
+    def step():
+        eng.disc_train(opts["disc"], data["x_labelled"], data["y_labelled"], data["x_generated"], data["c_generated"],
+                       data["mask_labelled"], data["mask_generated"])
+        c, _ = eng.infer_c(data["enc_word"], data["c_uniform"])
+        return eng.enc_gen_train((opts["enc"], opts["gen"]), data["enc_word"], data["enc_char"], data["dec_word"],
+                                 data["target"], c, data["eps"], kc, tau, calc_z_loss=args.z_loss)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ops.GEMM_PROFILE = {"variant": (128, 1, 1), "records": []}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = tt.item()
+    ce = losses[0].item()
+    if not (ce == ce) or ce <= 0:
+        raise SystemExit("non-finite loss in the benchmark step")
+
+    if rank == 0:
+        recs = prof["records"]
+        flops = sum(2.0 * M * N * K for _, _, M, N, K, _, _ in recs)
+        ms = sum(e0.elapsed_time(e1) for *_, e0, e1 in recs)
+        launches = len(recs)
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out = {
+            "metric": "wake-sleep training sentences/sec", "value": world * BATCH * args.steps / elapsed,
+            "unit": "sentences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "CGN full wake-sleep training step (disc step + c inference + enc/gen step + 3 Adam), "
+                                   "BASELINE configs[1]: vocab 20k, seq len 20, batch 64/GPU, emb 300, hidden 512, z 64, "
+                                   "fp32, calc_z_loss=%s" % args.z_loss,
+                       "global_batch": world * BATCH, "seq_len": SEQ, "parallelism": "dp%d" % world},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "gemm_kernel<128,true,true> (NT fp32 MFMA GEMM: all forward projections incl. the "
+                                   "vocabulary projection, and the fused dlogits GEMM)",
+                         "launches_per_step": launches / max(args.steps, 1),
+                         "avg_launch_us": 1e3 * ms / max(launches, 1),
+                         "algorithmic_gflop_per_step": flops / max(args.steps, 1) / 1e9},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(O, ocfg, host_data, global_step)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,6 +84,10 @@ typedef struct cgn_gemm_desc {
 } cgn_gemm_desc;
 
 int cgn_gemm_f32(void* stream, const cgn_gemm_desc* desc /* host */);
+/* Which kernel variant cgn_gemm_f32 would launch for `desc` (square tile 64|128, split-K factor, operand
+ * orientations); used by bench.py to attribute per-launch timings to kernel symbols. Launches nothing. */
+int cgn_gemm_plan(const cgn_gemm_desc* desc /* host */, int32_t* tile, int32_t* splitk, int32_t* a_kcontig,
+                  int32_t* b_kcontig);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Temperature softmax + NLL  (model/cgn.py:1086-1092: logits/tau -> F.log_softmax -> F.nll_loss, mean over ALL rows)

@@ -328,9 +328,55 @@ void launch(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t s)
         hipLaunchKernelGGL((gemm_kernel<BT, false, false>), grid, dim3(NT), 0, s, p);
 }
 
+// Tile / split-K heuristic: MI355X has 256 CUs and this kernel fits ~3-4 blocks per CU; aim for >= ~512 blocks.
+int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out) {
+    int bt = d->force_tile;
+    if (bt == 0) {
+        const long t128 = (long)cgn_cdiv(d->M, 128) * cgn_cdiv(d->N, 128);
+        bt = (t128 >= 384) ? 128 : 64;
+    }
+    const long tiles = (long)cgn_cdiv(d->M, bt) * cgn_cdiv(d->N, bt);
+    int splitk = d->force_splitk;
+    if (splitk <= 0) {
+        splitk = 1;
+        if (tiles < 256 && d->K >= 256) {
+            splitk = (int)((768 + tiles - 1) / tiles);
+            const int max_by_k = d->K / 128;  // keep >= 128 of K per split
+            if (splitk > max_by_k) splitk = max_by_k;
+            if (splitk < 1) splitk = 1;
+        }
+    }
+    if (splitk > 1) {
+        const long need = (long)splitk * d->M * d->N * (long)sizeof(float);
+        if (!d->workspace || d->workspace_bytes < need) {
+            if (d->force_splitk > 0) return CGN_ERR_WORKSPACE;
+            const long fit = d->workspace ? d->workspace_bytes / ((long)d->M * d->N * (long)sizeof(float)) : 0;
+            splitk = fit >= 2 ? (int)fit : 1;
+        }
+    }
+    int kps = cgn_cdiv(cgn_cdiv(d->K, splitk), BK) * BK;
+    if (kps < BK) kps = BK;
+    splitk = d->K > 0 ? cgn_cdiv(d->K, kps) : 1;
+    *bt_out = bt; *splitk_out = splitk; *kps_out = kps;
+    return CGN_OK;
+}
+
 }  // namespace
 
 extern "C" int cgn_abi_version(void) { return 1; }
+
+extern "C" int cgn_gemm_plan(const cgn_gemm_desc* d, int32_t* tile, int32_t* splitk, int32_t* a_kcontig,
+                             int32_t* b_kcontig) {
+    CGN_CHECK_ARG(d && tile && splitk && a_kcontig && b_kcontig);
+    CGN_CHECK_ARG(d->force_tile == 0 || d->force_tile == 64 || d->force_tile == 128);
+    int bt, sk, kps;
+    const int rc = plan_gemm(d, &bt, &sk, &kps);
+    if (rc) return rc;
+    *tile = bt; *splitk = sk;
+    *a_kcontig = (d->a_k.stride == 1 || d->a_m.stride != 1) ? 1 : 0;
+    *b_kcontig = (d->b_k.stride == 1 || d->b_n.stride != 1) ? 1 : 0;
+    return CGN_OK;
+}
 
 extern "C" int cgn_gemm_f32(void* stream, const cgn_gemm_desc* d) {
     CGN_CHECK_ARG(d != nullptr);
@@ -364,36 +410,14 @@ extern "C" int cgn_gemm_f32(void* stream, const cgn_gemm_desc* d) {
     p.a_vec = ((uintptr_t)d->A % 16 == 0) && (a_kc ? axis_vec_ok(d->a_k, d->a_m) : axis_vec_ok(d->a_m, d->a_k));
     p.b_vec = ((uintptr_t)d->B % 16 == 0) && (b_kc ? axis_vec_ok(d->b_k, d->b_n) : axis_vec_ok(d->b_n, d->b_k));
 
-    // Tile / split-K heuristic: MI355X has 256 CUs and this kernel fits ~4 blocks per CU; aim for >= ~512 blocks.
-    int bt = d->force_tile;
-    if (bt == 0) {
-        const long t128 = (long)cgn_cdiv(d->M, 128) * cgn_cdiv(d->N, 128);
-        bt = (t128 >= 384) ? 128 : 64;
+    int bt, splitk, kps;
+    {
+        const int rc = plan_gemm(d, &bt, &splitk, &kps);
+        if (rc) return rc;
     }
     p.tiles_m = cgn_cdiv(d->M, bt);
     p.tiles_n = cgn_cdiv(d->N, bt);
     const long tiles = (long)p.tiles_m * p.tiles_n;
-    int splitk = d->force_splitk;
-    if (splitk <= 0) {
-        splitk = 1;
-        if (tiles < 256 && d->K >= 256) {
-            splitk = (int)((768 + tiles - 1) / tiles);
-            const int max_by_k = d->K / 128;  // keep >= 128 of K per split
-            if (splitk > max_by_k) splitk = max_by_k;
-            if (splitk < 1) splitk = 1;
-        }
-    }
-    if (splitk > 1) {
-        const long need = (long)splitk * d->M * d->N * (long)sizeof(float);
-        if (!d->workspace || d->workspace_bytes < need) {
-            if (d->force_splitk > 0) return CGN_ERR_WORKSPACE;
-            const long fit = d->workspace ? d->workspace_bytes / ((long)d->M * d->N * (long)sizeof(float)) : 0;
-            splitk = fit >= 2 ? (int)fit : 1;
-        }
-    }
-    int kps = cgn_cdiv(cgn_cdiv(d->K, splitk), BK) * BK;
-    if (kps < BK) kps = BK;
-    splitk = d->K > 0 ? cgn_cdiv(d->K, kps) : 1;
     p.k_per_split = kps;
     p.splitk = splitk;
     p.ws = d->workspace;

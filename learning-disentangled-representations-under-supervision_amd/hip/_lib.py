@@ -69,6 +69,8 @@ ACT_TANH = 1
 PROTOTYPES = {
     "cgn_abi_version": (c_i32, []),
     "cgn_gemm_f32": (c_i32, [c_ptr, C.POINTER(GemmDesc)]),
+    "cgn_gemm_plan": (c_i32, [C.POINTER(GemmDesc), C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32),
+                              C.POINTER(c_i32)]),
     "cgn_softmax_nll_fwd_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_i32, c_f32, c_ptr, c_ptr, c_ptr]),
     "cgn_lstm_seq_fwd_f32": (c_i32, [c_ptr, C.POINTER(LstmFwdSeq), c_i32, c_i32, c_i32, c_i32]),
     "cgn_lstm_seq_bwd_f32": (c_i32, [c_ptr, C.POINTER(LstmBwdSeq), c_i32, c_i32, c_i32, c_i32]),

@@ -115,7 +115,6 @@ def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, 
     d.ldc = out.stride(0)
     d.alpha, d.beta = alpha, beta
     d.a_transform = _lib.ATRANS_NONE
-    keep = []
     if a_exp is not None:
         scale, lse = a_exp
         _chk_f32(lse, "lse")
@@ -141,10 +140,27 @@ def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, 
     d.workspace = _ptr(ws)
     d.workspace_bytes = ws.numel() * 4
     d.force_tile, d.force_splitk = force_tile, force_splitk
+    prof = GEMM_PROFILE
+    if prof is not None:
+        t_, s_, ak, bk = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(lib.cgn_gemm_plan(C.byref(d), C.byref(t_), C.byref(s_), C.byref(ak), C.byref(bk)), "cgn_gemm_plan")
+        key = (t_.value, ak.value, bk.value)
+        if prof["variant"] is None or prof["variant"] == key:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.device(dev):
+                e0.record()
+                _lib.check(lib.cgn_gemm_f32(_stream(), C.byref(d)), "cgn_gemm_f32")
+                e1.record()
+            prof["records"].append((key, s_.value, M, N, K, e0, e1))
+            return out
     with torch.cuda.device(dev):
         _lib.check(lib.cgn_gemm_f32(_stream(), C.byref(d)), "cgn_gemm_f32")
-    del keep
     return out
+
+
+# bench.py sets this to {"variant": (tile, a_kcontig, b_kcontig) or None, "records": []} to time GEMM launches with
+# HIP events on the launch stream; None (default) = no instrumentation.
+GEMM_PROFILE = None
 
 
 def softmax_nll_fwd(logits, target, inv_tau):

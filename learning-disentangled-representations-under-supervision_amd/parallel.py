@@ -1,0 +1,70 @@
+"""Data parallelism for the CGN step: one process per GPU, replicated weights, per-rank batch shard, gradient
+sum all-reduce (RCCL over xGMI on MI355X; gloo on CPU for tests) of each optimizer group's flat gradient arena right
+before that group's Adam step. The 1/world_size scaling is folded into the Adam kernel's gradient read.
+
+The reference has no distributed code; every loss of the step is a mean over independent sentences
+(§8e), so averaging per-rank gradients of equal-size shards equals one step over the concatenated batch.
+
+Buckets: xGMI is point-to-point, so a ring all-reduce is bound per link; a few large contiguous messages are used
+(BUCKET_BYTES) instead of one call per tensor. Buckets are issued asynchronously on RCCL's stream and waited for just
+before the Adam kernel, so the last GEMMs of the backward pass overlap the first buckets.
+"""
+import torch
+import torch.distributed as dist
+
+BUCKET_BYTES = 32 << 20
+
+
+class BucketedAllReduce:
+    def __init__(self, group=None, bucket_bytes=BUCKET_BYTES):
+        self.group = group
+        self.bucket_elems = max(1, bucket_bytes // 4)
+
+    def __call__(self, flat):
+        """Sum `flat` (1-D fp32 tensor) in place over all ranks."""
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return
+        n = flat.numel()
+        handles = []
+        for lo in range(0, n, self.bucket_elems):
+            hi = min(n, lo + self.bucket_elems)
+            handles.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for h in handles:
+            h.wait()  # on HIP: makes the current stream wait for the collective (no host block)
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract).
+    Returns (rank, world_size, local_rank)."""
+    import os
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_batch(tensors, rank, world):
+    """Rank r takes sentences [r*B/world, (r+1)*B/world) of every tensor whose first dim is the global batch."""
+    out = {}
+    for k, v in tensors.items():
+        B = v.shape[0]
+        if B % world:
+            raise ValueError("global batch %d not divisible by world size %d" % (B, world))
+        per = B // world
+        out[k] = v[rank * per:(rank + 1) * per].contiguous()
+    return out
+
+
+def attach(model, group=None):
+    """Make `model`'s fused step data-parallel over the initialised process group."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    model.set_data_parallel(BucketedAllReduce(group), world)
+    return world
