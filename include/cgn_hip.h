@@ -173,7 +173,7 @@ int cgn_conv_bwd_dw_f32(void* stream, const cgn_conv_widths* widths /* host */, 
 /* Embedding-table gradient (char_embed, selfModules/embedding.py:45 backward): dtable[v,:] = beta*dtable[v,:] +
  * sum_{pos: idx[pos]==v} dx[pos,:]; atomics-free, fixed order. */
 int cgn_embedding_bwd_f32(void* stream, const int64_t* idx, const float* dx, int32_t n, int32_t V, int32_t E, float beta,
-                          float* dtable);
+                          float* dtable, float* workspace /* >= 64*V*E floats */, int64_t workspace_bytes);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Streaming glue kernels.

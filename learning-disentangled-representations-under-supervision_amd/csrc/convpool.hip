@@ -162,17 +162,20 @@ __global__ __launch_bounds__(256) void conv_bwd_dw_kernel(const ConvWidths w, co
 }
 
 // Embedding-table gradient without atomics: dtable[v, :] (+)= sum over positions with idx == v of dx[pos, :].
-// One workgroup per table row; 16 position groups x 16 column lanes, fixed-order LDS reduction.
-__global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ idx, const float* __restrict__ dx,
-                                                            int n, int E, float beta, float* __restrict__ dtable) {
+// Stage 1: workgroup (v, chunk) scans its chunk of positions (16 position groups x 16 column lanes, fixed-order LDS
+// reduction) into part[chunk][v][:]; stage 2 sums the chunks in order. Bitwise reproducible.
+__global__ __launch_bounds__(256) void embedding_bwd_partial_kernel(const int64_t* __restrict__ idx,
+                                                                    const float* __restrict__ dx, int n, int V, int E,
+                                                                    int chunk_len, float* __restrict__ part) {
     __shared__ float red[16][17];
     const int v = blockIdx.x;
+    const int p0 = blockIdx.y * chunk_len, p1 = min(n, p0 + chunk_len);
     const int pg = threadIdx.x >> 4, el = threadIdx.x & 15;
     for (int e0 = 0; e0 < E; e0 += 16) {
         const int e = e0 + el;
         float s = 0.f;
         if (e < E) {
-            for (int pos = pg; pos < n; pos += 16)
+            for (int pos = p0 + pg; pos < p1; pos += 16)
                 if (idx[pos] == (int64_t)v) s += dx[(long)pos * E + e];
         }
         __syncthreads();
@@ -182,10 +185,17 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __res
             float t = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) t += red[k][el];
-            float* d = dtable + (long)v * E + e;
-            *d = (beta != 0.f) ? t + beta * (*d) : t;
+            part[((long)blockIdx.y * V + v) * E + e] = t;
         }
     }
+}
+__global__ __launch_bounds__(256) void embedding_bwd_final_kernel(const float* __restrict__ part, int nchunk, int VE,
+                                                                  float beta, float* __restrict__ dtable) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= VE) return;
+    float s = 0.f;
+    for (int c = 0; c < nchunk; ++c) s += part[(long)c * VE + i];
+    dtable[i] = (beta != 0.f) ? s + beta * dtable[i] : s;
 }
 
 int fill_widths(ConvWidths& cw, const cgn_conv_widths* d, bool need_w, bool need_dw) {
@@ -260,10 +270,19 @@ extern "C" int cgn_conv_bwd_dw_f32(void* stream, const cgn_conv_widths* widths, 
 }
 
 extern "C" int cgn_embedding_bwd_f32(void* stream, const int64_t* idx, const float* dx, int32_t n, int32_t V, int32_t E,
-                                     float beta, float* dtable) {
-    CGN_CHECK_ARG(n >= 0 && V >= 1 && E >= 1);
-    CGN_CHECK_ARG(idx && dx && dtable);
-    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, idx, dx, n, E, beta, dtable);
+                                     float beta, float* dtable, float* workspace, int64_t workspace_bytes) {
+    CGN_CHECK_ARG(n >= 0 && V >= 1 && E >= 1 && V <= 65535);
+    CGN_CHECK_ARG(idx && dx && dtable && workspace);
+    int nchunk = cgn_cdiv(n, 512);
+    if (nchunk > 64) nchunk = 64;
+    if (nchunk < 1) nchunk = 1;
+    if ((long)nchunk * V * E * 4 > workspace_bytes) return CGN_ERR_WORKSPACE;
+    const int chunk_len = cgn_cdiv(n > 0 ? n : 1, nchunk);
+    hipLaunchKernelGGL(embedding_bwd_partial_kernel, dim3(V, nchunk), dim3(256), 0, (hipStream_t)stream, idx, dx, n, V,
+                       E, chunk_len, workspace);
+    CGN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(embedding_bwd_final_kernel, dim3(cgn_cdiv((long)V * E, 256)), dim3(256), 0, (hipStream_t)stream,
+                       workspace, nchunk, V * E, beta, dtable);
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }

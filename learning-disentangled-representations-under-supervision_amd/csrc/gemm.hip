@@ -20,12 +20,14 @@ struct Axis {
     long stride, rpg, gs;
 };
 
-__device__ __forceinline__ long axis_off(const Axis& a, long i) {
+// indices and group sizes fit 32 bits (checked on the host): 32-bit division keeps the inlined code small
+__device__ __forceinline__ long axis_off(const Axis& a, int i) {
     if (a.rpg > 0) {
-        const long g = i / a.rpg;
-        return g * a.gs + (i - g * a.rpg) * a.stride;
+        const int r = (int)a.rpg;
+        const int g = i / r;
+        return (long)g * a.gs + (long)(i - g * r) * a.stride;
     }
-    return i * a.stride;
+    return (long)i * a.stride;
 }
 
 struct GemmParams {
@@ -107,41 +109,32 @@ struct TileLoader {
     }
 
     // Issue the global loads of the tile whose first k is k0 (k valid in [k0, kend)).
-    __device__ __forceinline__ void load(const float* __restrict__ base, const Axis& ak, int k0, int kend, bool vec,
-                                         int transform, float scale) {
+    // Every load is UNCONDITIONAL on a clamped (always valid) address; nothing here consumes the loaded registers, so
+    // the loads stay in flight under the MFMAs of the current tile. Invalid elements are zeroed (and the optional
+    // exp transform applied) in store(), right before the LDS write. (A branch around a load, or a select right after
+    // it, makes hipcc wait vmcnt(0) on the spot and serialises the L2 round trips.)
+    __device__ __forceinline__ void load(const float* __restrict__ base, const Axis& ak, int k0, int kend, bool vec) {
         const int tid = threadIdx.x;
+        const bool interior = k0 + BK <= kend;  // block-uniform: every k of this step is valid
         if constexpr (KC) {
             constexpr int QPR = BK / 4;
             const int q = tid % QPR;
             const int k = k0 + q * 4;
-            long koff[4];
-            if (vec) {
-                koff[0] = axis_off(ak, k);
+            if (vec && interior) {
+                const long koff = axis_off(ak, k);
+#pragma unroll
+                for (int i = 0; i < PER; ++i) regs[i] = *reinterpret_cast<const f32x4*>(base + roff[i] + koff);
             } else {
+                long koff[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) koff[j] = axis_off(ak, k + j);
-            }
+                for (int j = 0; j < 4; ++j) koff[j] = axis_off(ak, min(k + j, kend - 1));
 #pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (rok[i]) {
-                    if (vec && k + 3 < kend) {
-                        v = *reinterpret_cast<const f32x4*>(base + roff[i] + koff[0]);
-                    } else if (vec) {
+                for (int i = 0; i < PER; ++i) {
+                    f32x4 v;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (k + j < kend) v[j] = base[roff[i] + koff[0] + j];
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (k + j < kend) v[j] = base[roff[i] + koff[j]];
-                    }
-                    if (transform == CGN_ATRANS_EXP) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = (k + j < kend) ? expf(v[j] * scale - rparam[i]) : 0.f;
-                    }
+                    for (int j = 0; j < 4; ++j) v[j] = base[roff[i] + koff[j]];
+                    regs[i] = v;
                 }
-                regs[i] = v;
             }
         } else {
             constexpr int QPK = ROWS / 4;
@@ -150,25 +143,22 @@ struct TileLoader {
             const bool all_ok = rok[3];  // rows are increasing: last valid => all valid
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
-                const int k = k0 + kr + i * KS;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (k < kend) {
-                    const long koff = axis_off(ak, k);
-                    if (vec && all_ok) {
-                        v = *reinterpret_cast<const f32x4*>(base + roff[0] + koff);
-                    } else {
+                const int k = min(k0 + kr + i * KS, kend - 1);
+                const long koff = axis_off(ak, k);
+                f32x4 v;
+                if (vec && all_ok) {
+                    v = *reinterpret_cast<const f32x4*>(base + roff[0] + koff);
+                } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (rok[j]) v[j] = base[roff[j] + koff];
-                    }
+                    for (int j = 0; j < 4; ++j) v[j] = base[roff[j] + koff];  // roff of an invalid row is 0: in range
                 }
                 regs[i] = v;
             }
         }
     }
 
-    // Write the staged registers into the k-major LDS image dst[BK][ROWS + 1].
-    __device__ __forceinline__ void store(float* __restrict__ dst) const {
+    // Mask/transform the staged registers and write them into the k-major LDS image dst[BK][ROWS + 1].
+    __device__ __forceinline__ void store(float* __restrict__ dst, int k0, int kend, int transform, float scale) const {
         constexpr int LD = ROWS + 1;
         const int tid = threadIdx.x;
         if constexpr (KC) {
@@ -176,10 +166,16 @@ struct TileLoader {
             constexpr int RS = NT / QPR;
             const int q = tid % QPR;
             const int r = tid / QPR;
+            const int k = k0 + q * 4;
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dst[(q * 4 + j) * LD + r + i * RS] = regs[i][j];
+                for (int j = 0; j < 4; ++j) {
+                    float v = regs[i][j];
+                    if (transform == CGN_ATRANS_EXP) v = expf(v * scale - rparam[i]);
+                    v = (rok[i] && k + j < kend) ? v : 0.f;
+                    dst[(q * 4 + j) * LD + r + i * RS] = v;
+                }
             }
         } else {
             constexpr int QPK = ROWS / 4;
@@ -188,8 +184,9 @@ struct TileLoader {
             const int kr = tid / QPK;
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
+                const bool kok = k0 + kr + i * KS < kend;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dst[(kr + i * KS) * LD + rq * 4 + j] = regs[i][j];
+                for (int j = 0; j < 4; ++j) dst[(kr + i * KS) * LD + rq * 4 + j] = (kok && rok[j]) ? regs[i][j] : 0.f;
             }
         }
     }
@@ -240,10 +237,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmParams p) {
 
     const int nk = (kend - kbeg + BK - 1) / BK;
     if (nk > 0) {
-        la.load(p.A, p.ak, kbeg, kend, p.a_vec, p.a_transform, p.a_scale);
-        lb.load(p.B, p.bk, kbeg, kend, p.b_vec, 0, 0.f);
-        la.store(As);
-        lb.store(Bs);
+        la.load(p.A, p.ak, kbeg, kend, p.a_vec);
+        lb.load(p.B, p.bk, kbeg, kend, p.b_vec);
+        la.store(As, kbeg, kend, p.a_transform, p.a_scale);
+        lb.store(Bs, kbeg, kend, 0, 0.f);
     }
     __syncthreads();
 
@@ -251,28 +248,39 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmParams p) {
     const int fk = lane >> 5;  // k-slice within the 32x32x2 step
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
+        const int k_next = kbeg + (kt + 1) * BK;
         if (more) {
-            const int k0 = kbeg + (kt + 1) * BK;
-            la.load(p.A, p.ak, k0, kend, p.a_vec, p.a_transform, p.a_scale);
-            lb.load(p.B, p.bk, k0, kend, p.b_vec, 0, 0.f);
+            la.load(p.A, p.ak, k_next, kend, p.a_vec);
+            lb.load(p.B, p.bk, k_next, kend, p.b_vec);
         }
+        // fragment reads run one k-pair ahead of the MFMAs that consume them
+        float a_cur[TW], b_cur[TW], a_nxt[TW], b_nxt[TW];
+#pragma unroll
+        for (int i = 0; i < TW; ++i) a_cur[i] = As[fk * LD + wm * (BT / 2) + i * 32 + fr];
+#pragma unroll
+        for (int j = 0; j < TW; ++j) b_cur[j] = Bs[fk * LD + wn * (BT / 2) + j * 32 + fr];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            float a[TW], b[TW];
+            if (kk + 1 < BK / 2) {
 #pragma unroll
-            for (int i = 0; i < TW; ++i) a[i] = As[(kk * 2 + fk) * LD + wm * (BT / 2) + i * 32 + fr];
+                for (int i = 0; i < TW; ++i) a_nxt[i] = As[((kk + 1) * 2 + fk) * LD + wm * (BT / 2) + i * 32 + fr];
 #pragma unroll
-            for (int j = 0; j < TW; ++j) b[j] = Bs[(kk * 2 + fk) * LD + wn * (BT / 2) + j * 32 + fr];
+                for (int j = 0; j < TW; ++j) b_nxt[j] = Bs[((kk + 1) * 2 + fk) * LD + wn * (BT / 2) + j * 32 + fr];
+            }
 #pragma unroll
             for (int i = 0; i < TW; ++i)
 #pragma unroll
                 for (int j = 0; j < TW; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TW; ++i) a_cur[i] = a_nxt[i];
+#pragma unroll
+            for (int j = 0; j < TW; ++j) b_cur[j] = b_nxt[j];
         }
         __syncthreads();
         if (more) {
-            la.store(As);
-            lb.store(Bs);
+            la.store(As, k_next, kend, p.a_transform, p.a_scale);
+            lb.store(Bs, k_next, kend, 0, 0.f);
             __syncthreads();
         }
     }
@@ -330,21 +338,28 @@ void launch(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t s)
 
 // Tile / split-K heuristic: MI355X has 256 CUs and this kernel fits ~3-4 blocks per CU; aim for >= ~512 blocks.
 int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out) {
+    // Measured on MI355X (tools/gemm_bench.py): the kernel needs >= ~4 blocks per CU to keep the MFMA pipes fed, the
+    // 128-tile is the better choice once there are enough of them, and tall-K products want K split across blocks.
+    const long t128 = (long)cgn_cdiv(d->M, 128) * cgn_cdiv(d->N, 128);
+    const long t64 = (long)cgn_cdiv(d->M, 64) * cgn_cdiv(d->N, 64);
     int bt = d->force_tile;
-    if (bt == 0) {
-        const long t128 = (long)cgn_cdiv(d->M, 128) * cgn_cdiv(d->N, 128);
-        bt = (t128 >= 384) ? 128 : 64;
-    }
-    const long tiles = (long)cgn_cdiv(d->M, bt) * cgn_cdiv(d->N, bt);
     int splitk = d->force_splitk;
+    if (bt == 0) {
+        if (t128 >= 256 || (d->K >= 4096 && t128 >= 24))
+            bt = 128;
+        else
+            bt = 64;
+    }
+    const long tiles = bt == 128 ? t128 : t64;
     if (splitk <= 0) {
-        splitk = 1;
-        if (tiles < 256 && d->K >= 256) {
-            splitk = (int)((768 + tiles - 1) / tiles);
-            const int max_by_k = d->K / 128;  // keep >= 128 of K per split
-            if (splitk > max_by_k) splitk = max_by_k;
-            if (splitk < 1) splitk = 1;
-        }
+        const int min_k = bt == 128 ? 512 : 256;  // keep at least this much K per split
+        long want = (1024 + tiles - 1) / tiles;
+        const long max_by_k = d->K / min_k;
+        if (want > max_by_k) want = max_by_k;
+        // a split costs a slab round trip plus a reduce launch (~5 us): skip it for products under ~0.25 GFLOP
+        if ((double)d->M * d->N * d->K < 1.25e8) want = 1;
+        if (want < 1) want = 1;
+        splitk = (int)want;
     }
     if (splitk > 1) {
         const long need = (long)splitk * d->M * d->N * (long)sizeof(float);
@@ -384,6 +399,8 @@ extern "C" int cgn_gemm_f32(void* stream, const cgn_gemm_desc* d) {
     if (d->M == 0 || d->N == 0) return CGN_OK;
     CGN_CHECK_ARG(d->A && d->B && d->C);
     CGN_CHECK_ARG(d->ldc >= d->N);
+    CGN_CHECK_ARG(d->a_m.rpg < (1L << 31) && d->a_k.rpg < (1L << 31) && d->b_k.rpg < (1L << 31) &&
+                  d->b_n.rpg < (1L << 31));
     CGN_CHECK_ARG(d->a_transform == CGN_ATRANS_NONE || (d->a_transform == CGN_ATRANS_EXP && d->a_row_param));
     CGN_CHECK_ARG(d->epilogue == CGN_EPI_LINEAR || d->epilogue == CGN_EPI_SOFTMAX_BWD);
     if (d->epilogue == CGN_EPI_SOFTMAX_BWD)

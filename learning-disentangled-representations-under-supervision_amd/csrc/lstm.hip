@@ -6,7 +6,7 @@
 // [B,H]x[H,4H] product (134 MFLOP at B=64, H=512): latency-bound, so it is decomposed for parallelism, not tile size:
 //   * one workgroup = 16 batch rows x 16 hidden units (all four gates of those units), grid = (H/16, B/16, nseq)
 //     -> 256 workgroups (one per CU) for the encoder's two directions at cfg2;
-//   * its 4 waves split K four ways, each running v_mfma_f32_16x16x4_f32 chains on 4 independent accumulators
+//   * its 8 waves split K eight ways, each running v_mfma_f32_16x16x4_f32 chains on 4 independent accumulators
 //     (i, f, g, o tiles), then sum through LDS; the i/f/g/o of one (row, unit) land in the same lane/register of the
 //     four tiles, so the gate nonlinearities and the cell update need no cross-lane traffic;
 //   * operands are read straight from L2 into registers as float4 along k: lane (r, q) feeds k = 16s + 4q + i to the
@@ -39,7 +39,7 @@ struct FwdSeq {
 };
 struct FwdParams {
     FwdSeq s[LSTM_MAX_SEQ];
-    int B, T, H, step;
+    int B, T, H, step, nseq;
 };
 
 struct BwdSeq {
@@ -55,29 +55,56 @@ struct BwdSeq {
 };
 struct BwdParams {
     BwdSeq s[LSTM_MAX_SEQ];
-    int B, T, H, step;
+    int B, T, H, step, nseq;
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const FwdParams p) {
-    __shared__ float red[4][16][64];
-    const FwdSeq& sq = p.s[blockIdx.z];
+// XCD-aware work mapping. Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one), and every
+// (batch tile, sequence) of a hidden-unit tile reads the same W_hh rows. Give each XCD residue class a contiguous
+// range of hidden-unit tiles, so an XCD's L2 sees only 1/8 of W_hh instead of all of it (otherwise every step
+// re-streams 8 copies of the recurrent weights from the Infinity Cache). Placement only affects speed.
+struct WorkId {
+    int jt, bt, seq;
+};
+__device__ __forceinline__ WorkId lstm_work(int nj, int nb, int nseq) {
+    const int nwg = nj * nb * nseq;
+    const int bid = blockIdx.x;
+    const int qq = nwg / 8, rr = nwg % 8;
+    const int xcd = bid % 8, idx = bid / 8;
+    const int w = ((xcd < rr) ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;  // bijective
+    WorkId o;
+    o.jt = w / (nb * nseq);
+    const int rest = w % (nb * nseq);
+    o.bt = rest / nseq;
+    o.seq = rest % nseq;
+    return o;
+}
+
+constexpr int LSTM_NW = 8;            // waves per workgroup: K is split 8 ways
+constexpr int LSTM_NT = LSTM_NW * 64;
+
+// All global loads of a batch of chunks are issued unconditionally on clamped addresses BEFORE any of them is
+// consumed, so a wave has 20-32 16-byte loads in flight at once; the per-step latency is then ~one L2 round trip plus
+// the MFMA chain instead of one round trip per chunk.
+__global__ __launch_bounds__(LSTM_NT) void lstm_step_fwd_kernel(const FwdParams p) {
+    __shared__ float red[LSTM_NW][16][64];
     const int B = p.B, T = p.T, H = p.H;
+    const WorkId wk = lstm_work((H + 15) / 16, (B + 15) / 16, p.nseq);
+    const FwdSeq& sq = p.s[wk.seq];
     const int t = sq.reverse ? (T - 1 - p.step) : p.step;
     const int slot_prev = sq.reverse ? t + 1 : t;
     const int slot_out = sq.reverse ? t : t + 1;
-    const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int j0 = wk.jt * 16, b0 = wk.bt * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, q = lane >> 4;
 
     const int nchunks = (H + 15) / 16;
-    const int cpw = (nchunks + 3) / 4;
+    const int cpw = (nchunks + LSTM_NW - 1) / LSTM_NW;
     const int c_beg = wave * cpw, c_end = min(nchunks, c_beg + cpw);
 
-    const int bA = b0 + fr;  // A operand row
-    const int jB = j0 + fr;  // B operand column = hidden unit
-    const bool a_ok = bA < B, b_ok = jB < H;
+    const int bA = min(b0 + fr, B - 1);  // clamped operand row / column: out-of-range results are never stored
+    const int jB = min(j0 + fr, H - 1);
     const float* hrow = sq.hbuf + ((long)bA * (T + 1) + slot_prev) * H;
     const float* wrow = sq.w_hh + (long)jB * H;
     const long gate_stride = (long)H * H;
@@ -86,21 +113,29 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const FwdParams p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = {0.f, 0.f, 0.f, 0.f};
 
-    for (int c = c_beg; c < c_end; ++c) {
-        const int kb = c * 16 + q * 4;
-        const bool k_ok = kb < H;  // H % 4 == 0 (checked on the host), so kb < H implies kb + 3 < H
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        if (a_ok && k_ok) a = ld4(hrow + kb);
-        f32x4 w[4];
+    constexpr int CH = 4;
+    for (int c0 = c_beg; c0 < c_end; c0 += CH) {
+        f32x4 a[CH], w[4][CH];
+        bool kok[CH];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            w[g] = {0.f, 0.f, 0.f, 0.f};
-            if (b_ok && k_ok) w[g] = ld4(wrow + g * gate_stride + kb);
+        for (int u = 0; u < CH; ++u) {
+            const int kb = (c0 + u) * 16 + q * 4;
+            kok[u] = (c0 + u < c_end) && (kb < H);  // H % 4 == 0 (host check): kb < H implies kb + 3 < H
+            const int kc = kok[u] ? kb : 0;
+            a[u] = ld4(hrow + kc);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) w[g][u] = ld4(wrow + g * gate_stride + kc);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int u = 0; u < CH; ++u) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 au = kok[u] ? a[u] : z;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], w[g][i], acc[g], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(au[i], w[g][u][i], acc[g], 0, 0, 0);
+            }
         }
     }
 #pragma unroll
@@ -109,7 +144,8 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const FwdParams p) {
         for (int r = 0; r < 4; ++r) red[wave][g * 4 + r][lane] = acc[g][r];
     __syncthreads();
 
-    // thread (lane', r) finishes element (row = (lane'>>4)*4 + r, unit = lane'&15): C/D map of the 16x16 MFMA
+    // thread (lane', r) of the first 4 waves finishes element (row = (lane'>>4)*4 + r, unit = lane'&15)
+    if (wave >= 4) return;
     const int r = wave;
     const int b = b0 + (lane >> 4) * 4 + r;
     const int j = j0 + (lane & 15);
@@ -118,8 +154,9 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const FwdParams p) {
         const float* xg = sq.xg + ((long)b * T + t) * 4 * H;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float v = red[0][g * 4 + r][lane] + red[1][g * 4 + r][lane] + red[2][g * 4 + r][lane] +
-                      red[3][g * 4 + r][lane];
+            float v = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < LSTM_NW; ++wv) v += red[wv][g * 4 + r][lane];
             v += xg[g * H + j];
             if (sq.xg_extra) v += sq.xg_extra[(long)b * 4 * H + g * H + j];
             pre[g] = v;
@@ -141,66 +178,65 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const FwdParams p) {
     }
 }
 
-__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const BwdParams p) {
-    __shared__ float red[4][4][64];
-    const BwdSeq& sq = p.s[blockIdx.z];
+__global__ __launch_bounds__(LSTM_NT) void lstm_step_bwd_kernel(const BwdParams p) {
+    __shared__ float red[LSTM_NW][4][64];
     const int B = p.B, T = p.T, H = p.H;
+    const WorkId wk = lstm_work((H + 15) / 16, (B + 15) / 16, p.nseq);
+    const BwdSeq& sq = p.s[wk.seq];
     // processing order is the reverse of the forward pass
     const int t = sq.reverse ? p.step : (T - 1 - p.step);
     const int t_next = sq.reverse ? t - 1 : t + 1;  // the timestep processed just before this one
     const bool first = p.step == 0;
     const int slot_prev = sq.reverse ? t + 1 : t;
     const int slot_out = sq.reverse ? t : t + 1;
-    const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int j0 = wk.jt * 16, b0 = wk.bt * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, q = lane >> 4;
     const int K = 4 * H;
 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if (!first) {
-        const int nchunks = K / 16;  // H % 4 == 0 => 4H % 16 == 0
-        const int cpw = (nchunks + 3) / 4;
+        const int nchunks = K / 16;  // H % 4 == 0 => 4H % 16 == 0: every chunk is whole
+        const int cpw = (nchunks + LSTM_NW - 1) / LSTM_NW;
         const int c_beg = wave * cpw, c_end = min(nchunks, c_beg + cpw);
-        const int bA = b0 + fr, jB = j0 + fr;
-        const bool a_ok = bA < B, b_ok = jB < H;
+        const int bA = min(b0 + fr, B - 1), jB = min(j0 + fr, H - 1);
         const float* arow = sq.dgates + ((long)bA * T + t_next) * K;
         const float* wrow = sq.w_hh_t + (long)jB * K;
-        int c = c_beg;
-        for (; c + 1 < c_end; c += 2) {
-            const int kb0 = c * 16 + q * 4, kb1 = kb0 + 16;
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, w0 = a0, w1 = a0;
-            if (a_ok) {
-                a0 = ld4(arow + kb0);
-                a1 = ld4(arow + kb1);
-            }
-            if (b_ok) {
-                w0 = ld4(wrow + kb0);
-                w1 = ld4(wrow + kb1);
+        constexpr int CH = 8;
+        for (int c0 = c_beg; c0 < c_end; c0 += CH) {
+            f32x4 a[CH], w[CH];
+            bool kok[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                kok[u] = c0 + u < c_end;
+                const int kc = kok[u] ? (c0 + u) * 16 + q * 4 : 0;
+                a[u] = ld4(arow + kc);
+                w[u] = ld4(wrow + kc);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], w0[i], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i], w1[i], acc1, 0, 0, 0);
-            }
-        }
-        if (c < c_end) {
-            const int kb0 = c * 16 + q * 4;
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, w0 = a0;
-            if (a_ok) a0 = ld4(arow + kb0);
-            if (b_ok) w0 = ld4(wrow + kb0);
+            for (int u = 0; u < CH; u += 2) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 a0 = kok[u] ? a[u] : z, a1 = kok[u + 1] ? a[u + 1] : z;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], w0[i], acc0, 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], w[u][i], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i], w[u + 1][i], acc1, 0, 0, 0);
+                }
+            }
         }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc0[r] + acc1[r];
     __syncthreads();
 
+    if (wave >= 4) return;
     const int r = wave;
     const int b = b0 + (lane >> 4) * 4 + r;
     const int j = j0 + (lane & 15);
     if (b < B && j < H) {
-        float dh = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
+        float dh = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < LSTM_NW; ++wv) dh += red[wv][r][lane];
         if (first && sq.dh_seed) dh += sq.dh_seed[(long)b * H + j];
         if (sq.dh_ext) dh += sq.dh_ext[(long)b * sq.dh_bs + (long)t * sq.dh_ts + j];
         const float* gt = sq.gates + ((long)b * T + t) * K;
@@ -231,11 +267,11 @@ extern "C" int cgn_lstm_seq_fwd_f32(void* stream, const cgn_lstm_fwd_seq* seqs, 
         CGN_CHECK_ARG(((uintptr_t)s.hbuf % 16 == 0) && ((uintptr_t)s.w_hh % 16 == 0));
         p.s[i] = {s.xg, s.xg_extra, s.w_hh, s.hbuf, s.cbuf, s.gates, s.reverse};
     }
-    p.B = B; p.T = T; p.H = H;
-    dim3 grid(cgn_cdiv(H, 16), cgn_cdiv(B, 16), nseq);
+    p.B = B; p.T = T; p.H = H; p.nseq = nseq;
+    dim3 grid(cgn_cdiv(H, 16) * cgn_cdiv(B, 16) * nseq);
     for (int step = 0; step < T; ++step) {
         p.step = step;
-        hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(LSTM_NT), 0, (hipStream_t)stream, p);
     }
     CGN_LAUNCH_CHECK();
     return CGN_OK;
@@ -253,11 +289,11 @@ extern "C" int cgn_lstm_seq_bwd_f32(void* stream, const cgn_lstm_bwd_seq* seqs, 
         CGN_CHECK_ARG(((uintptr_t)s.dgates % 16 == 0) && ((uintptr_t)s.w_hh_t % 16 == 0));
         p.s[i] = {s.w_hh_t, s.cbuf, s.gates, s.dh_ext, s.dh_seed, s.dgates, s.dc_state, s.dh_bs, s.dh_ts, s.reverse};
     }
-    p.B = B; p.T = T; p.H = H;
-    dim3 grid(cgn_cdiv(H, 16), cgn_cdiv(B, 16), nseq);
+    p.B = B; p.T = T; p.H = H; p.nseq = nseq;
+    dim3 grid(cgn_cdiv(H, 16) * cgn_cdiv(B, 16) * nseq);
     for (int step = 0; step < T; ++step) {
         p.step = step;
-        hipLaunchKernelGGL(lstm_step_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(lstm_step_bwd_kernel, grid, dim3(LSTM_NT), 0, (hipStream_t)stream, p);
     }
     CGN_LAUNCH_CHECK();
     return CGN_OK;

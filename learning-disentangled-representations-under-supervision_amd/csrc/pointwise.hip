@@ -213,16 +213,17 @@ __global__ __launch_bounds__(PW_NT) void adam_kernel(float* __restrict__ p, cons
 //   featm = feat * mask (mask nullable)        logits[b,c] = featm[b,:] . W[c,:] + bias[c]
 //   ce  = mean_b( lse_b - logits[b, y_b] )     ent = -mean_b sum_c p log p
 //   dlogits[b,c] = w_ce/B * (p_c - [c == y_b]) + w_ent/B * ( -p_c (log p_c + H_b) )
-__global__ __launch_bounds__(256) void disc_head_kernel(const float* __restrict__ feat, long ldf,
+constexpr int DH_NT = 1024;
+__global__ __launch_bounds__(DH_NT) void disc_head_kernel(const float* __restrict__ feat, long ldf,
                                                         const float* __restrict__ mask, const float* __restrict__ W,
                                                         const float* __restrict__ bias, const int64_t* __restrict__ y,
                                                         int B, int F, float w_ce, float w_ent,
                                                         float* __restrict__ logits, float* __restrict__ p1,
                                                         float* __restrict__ dlogits, float* __restrict__ stats) {
-    __shared__ float red[8];
+    __shared__ float red[DH_NT / 64 + 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float ce_acc = 0.f, ent_acc = 0.f;
-    for (int b = wave; b < B; b += 4) {
+    for (int b = wave; b < B; b += DH_NT / 64) {
         float s0 = 0.f, s1 = 0.f;
         for (int f = lane; f < F; f += 64) {
             float x = feat[(long)b * ldf + f];
@@ -257,8 +258,8 @@ __global__ __launch_bounds__(256) void disc_head_kernel(const float* __restrict_
             }
         }
     }
-    ce_acc = block_sum<256>(ce_acc, red);
-    ent_acc = block_sum<256>(ent_acc, red);
+    ce_acc = block_sum<DH_NT>(ce_acc, red);
+    ent_acc = block_sum<DH_NT>(ent_acc, red);
     if (threadIdx.x == 0 && stats) {
         stats[0] = ce_acc / (float)B;
         stats[1] = ent_acc / (float)B;
@@ -513,7 +514,7 @@ extern "C" int cgn_disc_head_f32(void* stream, const float* feat, int64_t ldf, c
                                  float* logits, float* p1, float* dlogits, float* stats) {
     CGN_CHECK_ARG(B > 0 && F > 0 && ldf >= F);
     CGN_CHECK_ARG(feat && W && bias && logits);
-    hipLaunchKernelGGL(disc_head_kernel, dim3(1), dim3(256), 0, S_(stream), feat, (long)ldf, mask, W, bias, y, B, F, w_ce,
+    hipLaunchKernelGGL(disc_head_kernel, dim3(1), dim3(DH_NT), 0, S_(stream), feat, (long)ldf, mask, W, bias, y, B, F, w_ce,
                        w_ent, logits, p1, dlogits, stats);
     CGN_LAUNCH_CHECK();
     return CGN_OK;

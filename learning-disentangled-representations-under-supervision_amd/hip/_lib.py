@@ -79,7 +79,7 @@ PROTOTYPES = {
                                     c_i64]),
     "cgn_conv_bwd_dw_f32": (c_i32, [c_ptr, C.POINTER(ConvWidths), c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32,
                                     c_i32, c_f32]),
-    "cgn_embedding_bwd_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_f32, c_ptr]),
+    "cgn_embedding_bwd_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_f32, c_ptr, c_ptr, c_i64]),
     "cgn_copy2d_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_f32, c_f32]),
     "cgn_copy3d_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_i32, c_i32, c_i32, c_f32]),
     "cgn_float_to_index_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_ptr]),

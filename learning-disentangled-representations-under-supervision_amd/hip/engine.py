@@ -216,7 +216,10 @@ def lstm_param_grads(seq, dgates, x_operand, dW_ih, dW_hh, db_ih, db_hh, beta=0.
     hp, hk = seq.hprev_operand()
     ops.gemm(dg2.t(), hp, dW_hh, N=H, K=B * T, b_k=hk, b_n=LIN, beta=beta)
     ops.colsum(dg2, db_ih, beta=beta)
-    ops.colsum(dg2, db_hh, beta=beta)
+    if beta == 0.0:
+        ops.copy2d(db_ih.view(1, -1), db_hh.view(1, -1))  # both biases enter the gates additively: same gradient
+    else:
+        ops.colsum(dg2, db_hh, beta=beta)
     return dg2
 
 

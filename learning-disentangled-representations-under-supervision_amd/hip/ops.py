@@ -431,7 +431,8 @@ def embedding_bwd(idx, dx, dtable, beta=0.0):
     V, E = dtable.shape
     n = idx.numel()
     _req(dx.is_contiguous() and dx.numel() == n * E and dtable.is_contiguous(), "embedding_bwd shapes")
-    _call("cgn_embedding_bwd_f32", dx.device, _ptr(idx), _ptr(dx), n, V, E, beta, _ptr(dtable))
+    ws = workspace(dx.device)
+    _call("cgn_embedding_bwd_f32", dx.device, _ptr(idx), _ptr(dx), n, V, E, beta, _ptr(dtable), _ptr(ws), ws.numel() * 4)
 
 
 def lstm_seq_fwd(seqs, B, T, H):
