@@ -191,10 +191,11 @@ int cgn_transpose_f32(void* stream, const float* src, int32_t rows, int32_t cols
  * selfModules/embedding.py:42,57; mask = explicit word-dropout mask, model/generator.py:52; nullable). */
 int cgn_gather_rows_f32(void* stream, const float* table, int32_t V, int32_t E, const int64_t* idx, int32_t n,
                         const float* mask, float* out, int64_t ldo);
-/* Highway gate (selfModules/highway.py:38-44). pre = [N, 3S]: [nonlinear | linear | gate] pre-activations. */
-int cgn_highway_gate_fwd_f32(void* stream, const float* pre, int32_t N, int32_t S, float* out, int64_t ldo);
-int cgn_highway_gate_bwd_f32(void* stream, const float* pre, int32_t N, int32_t S, const float* dy, int64_t ldy,
-                             float* dpre);
+/* Highway gate (selfModules/highway.py:38-44). pre = [N, 3*Sp]: [nonlinear | linear | gate] pre-activation blocks of
+ * S columns at block stride Sp >= S (Sp a multiple of 4 keeps every block 16-byte aligned for the GEMMs). */
+int cgn_highway_gate_fwd_f32(void* stream, const float* pre, int32_t N, int32_t S, int32_t Sp, float* out, int64_t ldo);
+int cgn_highway_gate_bwd_f32(void* stream, const float* pre, int32_t N, int32_t S, int32_t Sp, const float* dy,
+                             int64_t ldy, float* dpre);
 /* Reparameterisation + KLD (model/cgn.py:94-101,1076-1080). mulv [B,2Z] = [mu|logvar]; zc [B,Z+C] = [z|c]. */
 int cgn_reparam_kld_fwd_f32(void* stream, const float* mulv, const float* eps, const float* c, int32_t B, int32_t Z,
                             int32_t C, float* zc, float* stdv, float* kld);

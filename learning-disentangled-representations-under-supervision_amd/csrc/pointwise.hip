@@ -78,31 +78,32 @@ __global__ __launch_bounds__(PW_NT) void gather_rows_kernel(const float* __restr
 }
 
 // ---- highway gate (selfModules/highway.py:38-44) ---------------------------------------------------------------
-// pre is [N, 3S]: columns [0,S) nonlinear pre-activation, [S,2S) linear, [2S,3S) gate pre-activation.
-__global__ __launch_bounds__(PW_NT) void highway_fwd_kernel(const float* __restrict__ pre, int N, int S,
+// pre is [N, 3*Sp] (Sp >= S, the 16-byte aligned block stride): columns [0,S) nonlinear pre-activation,
+// [Sp,Sp+S) linear, [2Sp,2Sp+S) gate pre-activation.
+__global__ __launch_bounds__(PW_NT) void highway_fwd_kernel(const float* __restrict__ pre, int N, int S, int Sp,
                                                             float* __restrict__ out, long ldo) {
     const long total = (long)N * S;
     for (long i = (long)blockIdx.x * PW_NT + threadIdx.x; i < total; i += (long)gridDim.x * PW_NT) {
         const int r = (int)(i / S), c = (int)(i % S);
-        const float* p = pre + (long)r * 3 * S;
-        const float nl = fmaxf(p[c], 0.f), li = p[S + c], g = cgn_sigmoid(p[2 * S + c]);
+        const float* p = pre + (long)r * 3 * Sp;
+        const float nl = fmaxf(p[c], 0.f), li = p[Sp + c], g = cgn_sigmoid(p[2 * Sp + c]);
         out[(long)r * ldo + c] = g * nl + (1.f - g) * li;
     }
 }
 
-__global__ __launch_bounds__(PW_NT) void highway_bwd_kernel(const float* __restrict__ pre, int N, int S,
+__global__ __launch_bounds__(PW_NT) void highway_bwd_kernel(const float* __restrict__ pre, int N, int S, int Sp,
                                                             const float* __restrict__ dy, long ldy,
                                                             float* __restrict__ dpre) {
     const long total = (long)N * S;
     for (long i = (long)blockIdx.x * PW_NT + threadIdx.x; i < total; i += (long)gridDim.x * PW_NT) {
         const int r = (int)(i / S), c = (int)(i % S);
-        const float* p = pre + (long)r * 3 * S;
-        float* d = dpre + (long)r * 3 * S;
-        const float n = p[c], li = p[S + c], g = cgn_sigmoid(p[2 * S + c]);
+        const float* p = pre + (long)r * 3 * Sp;
+        float* d = dpre + (long)r * 3 * Sp;
+        const float n = p[c], li = p[Sp + c], g = cgn_sigmoid(p[2 * Sp + c]);
         const float g_y = dy[(long)r * ldy + c];
         d[c] = (n > 0.f) ? g_y * g : 0.f;
-        d[S + c] = g_y * (1.f - g);
-        d[2 * S + c] = g_y * (fmaxf(n, 0.f) - li) * g * (1.f - g);
+        d[Sp + c] = g_y * (1.f - g);
+        d[2 * Sp + c] = g_y * (fmaxf(n, 0.f) - li) * g * (1.f - g);
     }
 }
 
@@ -417,22 +418,23 @@ extern "C" int cgn_gather_rows_f32(void* stream, const float* table, int32_t V, 
     return CGN_OK;
 }
 
-extern "C" int cgn_highway_gate_fwd_f32(void* stream, const float* pre, int32_t N, int32_t S, float* out, int64_t ldo) {
-    CGN_CHECK_ARG(N >= 0 && S > 0);
+extern "C" int cgn_highway_gate_fwd_f32(void* stream, const float* pre, int32_t N, int32_t S, int32_t Sp, float* out,
+                                        int64_t ldo) {
+    CGN_CHECK_ARG(N >= 0 && S > 0 && Sp >= S);
     if (N == 0) return CGN_OK;
     CGN_CHECK_ARG(pre && out && ldo >= S);
-    hipLaunchKernelGGL(highway_fwd_kernel, dim3(pw_blocks((long)N * S)), dim3(PW_NT), 0, S_(stream), pre, N, S, out,
+    hipLaunchKernelGGL(highway_fwd_kernel, dim3(pw_blocks((long)N * S)), dim3(PW_NT), 0, S_(stream), pre, N, S, Sp, out,
                        (long)ldo);
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }
 
-extern "C" int cgn_highway_gate_bwd_f32(void* stream, const float* pre, int32_t N, int32_t S, const float* dy,
-                                        int64_t ldy, float* dpre) {
-    CGN_CHECK_ARG(N >= 0 && S > 0);
+extern "C" int cgn_highway_gate_bwd_f32(void* stream, const float* pre, int32_t N, int32_t S, int32_t Sp,
+                                        const float* dy, int64_t ldy, float* dpre) {
+    CGN_CHECK_ARG(N >= 0 && S > 0 && Sp >= S);
     if (N == 0) return CGN_OK;
     CGN_CHECK_ARG(pre && dy && dpre && ldy >= S);
-    hipLaunchKernelGGL(highway_bwd_kernel, dim3(pw_blocks((long)N * S)), dim3(PW_NT), 0, S_(stream), pre, N, S, dy,
+    hipLaunchKernelGGL(highway_bwd_kernel, dim3(pw_blocks((long)N * S)), dim3(PW_NT), 0, S_(stream), pre, N, S, Sp, dy,
                        (long)ldy, dpre);
     CGN_LAUNCH_CHECK();
     return CGN_OK;

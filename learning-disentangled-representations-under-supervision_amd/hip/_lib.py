@@ -86,8 +86,8 @@ PROTOTYPES = {
     "cgn_mahalanobis_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_f32, c_ptr, c_ptr]),
     "cgn_transpose_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_ptr]),
     "cgn_gather_rows_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i64]),
-    "cgn_highway_gate_fwd_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i64]),
-    "cgn_highway_gate_bwd_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
+    "cgn_highway_gate_fwd_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_i64]),
+    "cgn_highway_gate_bwd_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
     "cgn_reparam_kld_fwd_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr]),
     "cgn_reparam_kld_bwd_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_i32, c_i32, c_ptr]),
     "cgn_colsum_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_i32, c_f32, c_ptr, c_ptr, c_i64]),

@@ -18,18 +18,31 @@ class ParamArena:
         self.names = [n for n, _ in named_params]
         self.offsets, off = {}, 0
         for n, p in named_params:
-            self.offsets[n] = (off, p.numel(), tuple(p.shape))
-            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            shape = tuple(p.shape)
+            # big matrices whose rows are not a multiple of 4 floats (e.g. [*, 825] highway / LSTM input weights,
+            # [*, 365] generator input weights) get a padded row stride so that GEMM operand rows are 16-byte aligned
+            ld = shape[-1]
+            if p.dim() == 2 and shape[0] >= 64 and shape[1] >= 64 and shape[1] % 4:
+                ld = (shape[1] + 3) // 4 * 4
+            ne = p.numel() // shape[-1] * ld if p.dim() >= 1 and shape[-1] else p.numel()
+            self.offsets[n] = (off, ne, shape, ld)
+            off += (ne + ALIGN - 1) // ALIGN * ALIGN
         self.size = off
         self.p = torch.zeros(off, dtype=torch.float32, device=device)
         self.g = torch.zeros(off, dtype=torch.float32, device=device)
         self.params, self.grads = {}, {}
         for n, p in named_params:
-            o, ne, shape = self.offsets[n]
-            view = self.p[o:o + ne].view(shape)
+            o, ne, shape, ld = self.offsets[n]
+
+            def carve(flat):
+                if len(shape) == 2 and ld != shape[1]:
+                    return flat[o:o + ne].view(shape[0], ld)[:, :shape[1]]
+                return flat[o:o + ne].view(shape)
+
+            view = carve(self.p)
             view.copy_(p.data)
             p.data = view
-            gview = self.g[o:o + ne].view(shape)
+            gview = carve(self.g)
             p.grad = gview
             self.params[n] = p
             self.grads[n] = gview

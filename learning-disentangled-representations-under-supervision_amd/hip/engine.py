@@ -98,16 +98,18 @@ def tdnn_bwd(saved, kernels, dfeat, dkernels, dchar_table, beta=0.0):
 # highway (selfModules/highway.py:27-46), f = relu as used by the encoder (model/encoder.py:15)
 # ------------------------------------------------------------------------------------------------------------------
 def highway_fwd(x, layers):
-    """x [N,S]; layers: list of dict(nw, nb, lw, lb, gw, gb). Returns y and the per-layer saved (input, pre)."""
+    """x [N,S]; layers: list of dict(nw, nb, lw, lb, gw, gb). Returns y and the per-layer saved (input, pre).
+    Activations live in buffers whose rows/blocks start on 16-byte boundaries (S = 825 is odd in the reference)."""
     N, S = x.shape
+    Sp = ops.pad4(S)
     saved = []
     for p in layers:
-        pre = _new((N, 3 * S), x.device)
+        pre = _new((N, 3 * Sp), x.device)
         ops.gemm(x, p["nw"].t(), pre[:, 0:S], bias0=p["nb"])
-        ops.gemm(x, p["lw"].t(), pre[:, S:2 * S], bias0=p["lb"])
-        ops.gemm(x, p["gw"].t(), pre[:, 2 * S:3 * S], bias0=p["gb"])
-        y = _new((N, S), x.device)
-        ops.highway_gate_fwd(pre, y)
+        ops.gemm(x, p["lw"].t(), pre[:, Sp:Sp + S], bias0=p["lb"])
+        ops.gemm(x, p["gw"].t(), pre[:, 2 * Sp:2 * Sp + S], bias0=p["gb"])
+        y = ops.new2d(N, S, x.device)
+        ops.highway_gate_fwd(pre, S, y)
         saved.append((x, pre))
         x = y
     return x, saved
@@ -120,16 +122,17 @@ def highway_bwd(saved, layers, dy, grads, need_dx, beta=0.0):
         x, pre = saved[li]
         p = layers[li]
         N, S = x.shape
-        dpre = _new((N, 3 * S), x.device)
-        ops.highway_gate_bwd(pre, dy, dpre)
-        views = (dpre[:, 0:S], dpre[:, S:2 * S], dpre[:, 2 * S:3 * S])
+        Sp = pre.shape[1] // 3
+        dpre = _new((N, 3 * Sp), x.device)
+        ops.highway_gate_bwd(pre, S, dy, dpre)
+        views = (dpre[:, 0:S], dpre[:, Sp:Sp + S], dpre[:, 2 * Sp:2 * Sp + S])
         if grads is not None:
             g = grads[li]
             for v, wn, bn in zip(views, ("nw", "lw", "gw"), ("nb", "lb", "gb")):
                 ops.gemm(v.t(), x, g[wn], beta=beta)
                 ops.colsum(v, g[bn], beta=beta)
         if li > 0 or need_dx:
-            dx = _new((N, S), x.device)
+            dx = ops.new2d(N, S, x.device)
             ops.gemm(views[0], p["nw"], dx)
             ops.gemm(views[1], p["lw"], dx, beta=1.0)
             ops.gemm(views[2], p["gw"], dx, beta=1.0)

@@ -238,24 +238,34 @@ def gather_rows(table, idx, out, mask=None):
     return out
 
 
-def highway_gate_fwd(pre, out):
+def pad4(n):
+    return (n + 3) // 4 * 4
+
+
+def new2d(rows, cols, dev):
+    """[rows, cols] fp32 view whose row stride is a multiple of 4 floats (16-byte aligned rows for float4 GEMM loads)."""
+    return torch.empty((rows, pad4(cols)), dtype=torch.float32, device=dev)[:, :cols]
+
+
+def highway_gate_fwd(pre, S, out):
+    """pre [N, 3*Sp] contiguous with Sp = pre.shape[1] // 3 >= S; out [N, S]."""
     _chk_f32(pre, "pre")
-    N, S3 = pre.shape
-    S = S3 // 3
+    N, Sp3 = pre.shape
+    Sp = Sp3 // 3
     ldo = _rows2d(out, "out")
-    _req(pre.is_contiguous() and S3 == 3 * S and out.shape == (N, S), "highway_gate_fwd shapes")
-    _call("cgn_highway_gate_fwd_f32", out.device, _ptr(pre), N, S, _ptr(out), ldo)
+    _req(pre.is_contiguous() and Sp3 == 3 * Sp and Sp >= S and out.shape == (N, S), "highway_gate_fwd shapes")
+    _call("cgn_highway_gate_fwd_f32", out.device, _ptr(pre), N, S, Sp, _ptr(out), ldo)
     return out
 
 
-def highway_gate_bwd(pre, dy, dpre):
+def highway_gate_bwd(pre, S, dy, dpre):
     _chk_f32(pre, "pre"), _chk_f32(dpre, "dpre")
-    N, S3 = pre.shape
-    S = S3 // 3
+    N, Sp3 = pre.shape
+    Sp = Sp3 // 3
     ldy = _rows2d(dy, "dy")
-    _req(pre.is_contiguous() and dpre.is_contiguous() and dpre.shape == pre.shape and dy.shape == (N, S),
+    _req(pre.is_contiguous() and dpre.is_contiguous() and dpre.shape == pre.shape and Sp >= S and dy.shape == (N, S),
          "highway_gate_bwd shapes")
-    _call("cgn_highway_gate_bwd_f32", dpre.device, _ptr(pre), N, S, _ptr(dy), ldy, _ptr(dpre))
+    _call("cgn_highway_gate_bwd_f32", dpre.device, _ptr(pre), N, S, Sp, _ptr(dy), ldy, _ptr(dpre))
     return dpre
 
 

@@ -189,10 +189,10 @@ class CGNStep:
                                        [None, None], [None, None], [dcf, dcr])
         hw_out = es["hw_out"]
         Din = hw_out.shape[1]
-        dhw = _new((N, Din), self.dev)
+        dhw = ops.new2d(N, Din, self.dev)
         for i, (s, dg, sfx) in enumerate(((sf, dgf, ""), (sr, dgr, "_reverse"))):
             if param_grads:
-                dg2 = engine.lstm_param_grads(s, dg, (hw_out, Axis(Din, 0, 0)), G["encoder.rnn.weight_ih_l0" + sfx],
+                dg2 = engine.lstm_param_grads(s, dg, (hw_out, Axis(hw_out.stride(0), 0, 0)), G["encoder.rnn.weight_ih_l0" + sfx],
                                               G["encoder.rnn.weight_hh_l0" + sfx], G["encoder.rnn.bias_ih_l0" + sfx],
                                               G["encoder.rnn.bias_hh_l0" + sfx])
             else:
@@ -223,7 +223,7 @@ class CGNStep:
             raise RuntimeError("Kernel size can't be greater than actual input size")
 
         # ---- embedding (selfModules/embedding.py:29-55) --------------------------------------------------------
-        enc_in = _new((N, Din), dev)
+        enc_in = ops.new2d(N, Din, dev)
         ops.gather_rows(table, enc_word.reshape(-1), enc_in[:, :E])
         tk = self._tdnn_kernels(P)
         tfeat, tsaved = engine.tdnn_fwd(enc_char.reshape(N, Wl), P["embedding.char_embed.weight"], tk)
@@ -286,8 +286,8 @@ class CGNStep:
                                 arg_d, B, L, E, d_out_emb, T * E)
         if calc_z_loss:
             # ---- z reconstruction through the encoder (cgn.py:1122-1137) ------------------------------------------
-            enc_in2 = _new((N, Din), dev)
-            ops.copy3d(out_emb.view(B, T, E)[:, :L], enc_in2.view(B, L, Din)[:, :, :E])
+            enc_in2 = ops.new2d(N, Din, dev)
+            ops.copy3d(out_emb.view(B, T, E)[:, :L], enc_in2.unflatten(0, (B, L))[:, :, :E])
             ops.copy2d(tfeat, enc_in2[:, E:])
             es2 = self._encoder_fwd(enc_in2, B, L)
             dmulv2 = _new((B, 2 * Z), dev)
@@ -295,7 +295,7 @@ class CGNStep:
             if train:
                 d_enc_in2 = self._encoder_bwd(es2, dmulv2, param_grads=False)
                 # add the word-part gradient into d_out_emb rows (b, t < L)
-                ops.add3d(d_enc_in2.view(B, L, Din)[:, :, :E], d_out_emb.view(B, T, E)[:, :L])
+                ops.add3d(d_enc_in2.unflatten(0, (B, L))[:, :, :E], d_out_emb.view(B, T, E)[:, :L])
         enc_loss = ops.lincomb([(79.0, ce), (float(kld_coeff), kld)])  # cgn.py:1151
         gen_loss = ops.lincomb([(1.0, enc_loss), (cfg.lambda_c if use_disc else 0.0, c_loss),
                                 (cfg.lambda_z if calc_z_loss else 0.0, z_loss)])  # cgn.py:1152
