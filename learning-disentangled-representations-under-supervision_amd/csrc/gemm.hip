@@ -52,7 +52,7 @@ struct GemmParams {
     float alpha, beta, a_scale, ep_inv_tau, ep_ce_scale;
 };
 
-constexpr int BK = 32;
+constexpr int KROUND = 32;  // split-K ranges are multiples of every BK in use
 constexpr int NT = 256;
 
 __device__ __forceinline__ float apply_epilogue(const GemmParams& p, int row, int col, float acc) {
@@ -68,18 +68,25 @@ __device__ __forceinline__ float apply_epilogue(const GemmParams& p, int row, in
     return v;
 }
 
-// Operand tile loader. The tile is ROWS (m or n index) x BK (k index).
-//   KC = true : memory is contiguous along k (row-major [rows][k])  -> lanes run along k, float4 along k
-//   KC = false: memory is contiguous along the row index ([k][rows]) -> lanes run along rows, float4 along rows
-template <int ROWS, bool KC>
+// Operand tile loader. The tile is ROWS (m or n index) x BK (k index); its LDS image is row-major [ROWS][LDK] with
+// LDK = BK + 4 floats (144-byte rows): the MFMA loop reads a lane's 4 consecutive k of one row with ONE ds_read_b128
+// (rows 144 B apart put 16 consecutive rows on 16 different 16-byte slots of the 256-byte bank row: conflict-free),
+// and every staging write is a ds_write_b128 of 4 consecutive k of one row.
+//   KC = true : memory is contiguous along k (row-major [rows][k]): thread = (row, k-quad), one float4 load per chunk
+//   KC = false: memory is contiguous along the row index ([k][rows]): thread = one row, lanes run along rows, scalar
+//               loads (a wave covers 64 consecutive rows = 256 contiguous bytes per k), 4 k per chunk
+template <int ROWS, bool KC, int BK>
 struct TileLoader {
-    static constexpr int QUADS = ROWS * BK / 4;  // float4 chunks per tile
+    static constexpr int LDK = BK + 4;
+    static constexpr int QUADS = ROWS * BK / 4;  // 4-k chunks per tile
     static constexpr int PER = QUADS / NT;       // chunks per thread
     static_assert(QUADS % NT == 0, "tile/threads mismatch");
+    static constexpr int KGROUPS = NT / ROWS;    // !KC: thread groups along k
+    static_assert(KC || (BK / KGROUPS == 4 * PER), "k coverage");
 
     f32x4 regs[PER];
-    long roff[KC ? PER : 4];  // KC: per-chunk row offsets; !KC: offsets of the 4 rows of this thread's quad
-    bool rok[KC ? PER : 4];
+    long roff[KC ? PER : 1];
+    bool rok[KC ? PER : 1];
     float rparam[KC ? PER : 1];
 
     __device__ __forceinline__ void init(const Axis& ar, int r0, int rlimit, int transform, const float* row_param) {
@@ -92,18 +99,13 @@ struct TileLoader {
             for (int i = 0; i < PER; ++i) {
                 const int row = r0 + r + i * RS;
                 rok[i] = row < rlimit;
-                roff[i] = rok[i] ? axis_off(ar, row) : 0;
+                roff[i] = rok[i] ? axis_off(ar, row) : 0;  // clamped: row 0 of the operand is always addressable
                 rparam[i] = (transform && rok[i]) ? row_param[row] : 0.f;
             }
         } else {
-            constexpr int QPK = ROWS / 4;  // quads per k
-            const int rq = tid % QPK;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = r0 + rq * 4 + j;
-                rok[j] = row < rlimit;
-                roff[j] = rok[j] ? axis_off(ar, row) : 0;
-            }
+            const int row = r0 + tid % ROWS;
+            rok[0] = row < rlimit;
+            roff[0] = rok[0] ? axis_off(ar, row) : 0;
             rparam[0] = 0.f;
         }
     }
@@ -115,11 +117,11 @@ struct TileLoader {
     // it, makes hipcc wait vmcnt(0) on the spot and serialises the L2 round trips.)
     __device__ __forceinline__ void load(const float* __restrict__ base, const Axis& ak, int k0, int kend, bool vec) {
         const int tid = threadIdx.x;
-        const bool interior = k0 + BK <= kend;  // block-uniform: every k of this step is valid
         if constexpr (KC) {
             constexpr int QPR = BK / 4;
             const int q = tid % QPR;
             const int k = k0 + q * 4;
+            const bool interior = k0 + BK <= kend;  // block-uniform: every k of this step is valid
             if (vec && interior) {
                 const long koff = axis_off(ak, k);
 #pragma unroll
@@ -137,29 +139,20 @@ struct TileLoader {
                 }
             }
         } else {
-            constexpr int QPK = ROWS / 4;
-            constexpr int KS = NT / QPK;
-            const int kr = tid / QPK;
-            const bool all_ok = rok[3];  // rows are increasing: last valid => all valid
+            const int kb = k0 + (tid / ROWS) * (4 * PER);  // wave-uniform
+            const float* rb = base + roff[0];
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
-                const int k = min(k0 + kr + i * KS, kend - 1);
-                const long koff = axis_off(ak, k);
                 f32x4 v;
-                if (vec && all_ok) {
-                    v = *reinterpret_cast<const f32x4*>(base + roff[0] + koff);
-                } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = base[roff[j] + koff];  // roff of an invalid row is 0: in range
-                }
+                for (int j = 0; j < 4; ++j) v[j] = rb[axis_off(ak, min(kb + 4 * i + j, kend - 1))];
                 regs[i] = v;
             }
         }
     }
 
-    // Mask/transform the staged registers and write them into the k-major LDS image dst[BK][ROWS + 1].
+    // Mask/transform the staged registers and write them into the LDS image dst[ROWS][LDK].
     __device__ __forceinline__ void store(float* __restrict__ dst, int k0, int kend, int transform, float scale) const {
-        constexpr int LD = ROWS + 1;
         const int tid = threadIdx.x;
         if constexpr (KC) {
             constexpr int QPR = BK / 4;
@@ -169,24 +162,24 @@ struct TileLoader {
             const int k = k0 + q * 4;
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
+                f32x4 v = regs[i];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float v = regs[i][j];
-                    if (transform == CGN_ATRANS_EXP) v = expf(v * scale - rparam[i]);
-                    v = (rok[i] && k + j < kend) ? v : 0.f;
-                    dst[(q * 4 + j) * LD + r + i * RS] = v;
+                    float x = v[j];
+                    if (transform == CGN_ATRANS_EXP) x = expf(x * scale - rparam[i]);
+                    v[j] = (rok[i] && k + j < kend) ? x : 0.f;
                 }
+                *reinterpret_cast<f32x4*>(dst + (r + i * RS) * LDK + q * 4) = v;
             }
         } else {
-            constexpr int QPK = ROWS / 4;
-            constexpr int KS = NT / QPK;
-            const int rq = tid % QPK;
-            const int kr = tid / QPK;
+            const int row = tid % ROWS;
+            const int kl = (tid / ROWS) * (4 * PER);
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
-                const bool kok = k0 + kr + i * KS < kend;
+                f32x4 v = regs[i];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dst[(kr + i * KS) * LD + rq * 4 + j] = (kok && rok[j]) ? regs[i][j] : 0.f;
+                for (int j = 0; j < 4; ++j) v[j] = (rok[0] && k0 + kl + 4 * i + j < kend) ? v[j] : 0.f;
+                *reinterpret_cast<f32x4*>(dst + row * LDK + kl + 4 * i) = v;
             }
         }
     }
@@ -201,12 +194,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return start + idx;
 }
 
-template <int BT, bool A_KC, bool B_KC>
+// BK: 16 for the 128-tile (3 blocks/CU by LDS and registers), 32 for the 64-tile (measured, tools/gemm_bench.py)
+template <int BT, bool A_KC, bool B_KC, int ABL = 0, int BK = (BT == 128 ? 16 : 32)>
 __global__ __launch_bounds__(NT) void gemm_kernel(const GemmParams p) {
     constexpr int TW = BT / 64;  // 32x32 accumulators per wave along each dim
-    constexpr int LD = BT + 1;
-    __shared__ float As[BK * LD];
-    __shared__ float Bs[BK * LD];
+    constexpr int LDK = BK + 4;  // LDS row stride (floats) of both operand images
+    // One LDS array (both operands, two buffers): keeps every carve offset explicit and 16-byte aligned.
+    constexpr int TILE = BT * LDK;  // floats per operand image
+    __shared__ __attribute__((aligned(16))) float lds[4 * TILE];
 
     const int ntiles = p.tiles_m * p.tiles_n;
     const int t = xcd_remap(blockIdx.x, ntiles);
@@ -222,8 +217,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmParams p) {
     const int wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    TileLoader<BT, A_KC> la;
-    TileLoader<BT, B_KC> lb;
+    TileLoader<BT, A_KC, BK> la;
+    TileLoader<BT, B_KC, BK> lb;
     la.init(p.am, m0, p.M, p.a_transform, p.a_row_param);
     lb.init(p.bn, n0, p.N, 0, nullptr);
 
@@ -235,54 +230,79 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Pipeline (one barrier per K step, global loads a full step ahead, LDS double-buffered):
+    //   step kt:  write tile kt+1 (registers, loaded during step kt-1) into buf[(kt+1)&1]
+    //             issue the global loads of tile kt+2 into the staging registers
+    //             MFMAs on buf[kt&1]
+    //             barrier
     const int nk = (kend - kbeg + BK - 1) / BK;
     if (nk > 0) {
         la.load(p.A, p.ak, kbeg, kend, p.a_vec);
         lb.load(p.B, p.bk, kbeg, kend, p.b_vec);
-        la.store(As, kbeg, kend, p.a_transform, p.a_scale);
-        lb.store(Bs, kbeg, kend, 0, 0.f);
+        la.store(lds, kbeg, kend, p.a_transform, p.a_scale);
+        lb.store(lds + TILE, kbeg, kend, 0, 0.f);
+        if (nk > 1) {
+            la.load(p.A, p.ak, kbeg + BK, kend, p.a_vec);
+            lb.load(p.B, p.bk, kbeg + BK, kend, p.b_vec);
+        }
     }
     __syncthreads();
 
     const int fr = lane & 31;  // fragment row/col
     const int fk = lane >> 5;  // k-slice within the 32x32x2 step
     for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        const int k_next = kbeg + (kt + 1) * BK;
-        if (more) {
-            la.load(p.A, p.ak, k_next, kend, p.a_vec);
-            lb.load(p.B, p.bk, k_next, kend, p.b_vec);
-        }
-        // fragment reads run one k-pair ahead of the MFMAs that consume them
-        float a_cur[TW], b_cur[TW], a_nxt[TW], b_nxt[TW];
-#pragma unroll
-        for (int i = 0; i < TW; ++i) a_cur[i] = As[fk * LD + wm * (BT / 2) + i * 32 + fr];
-#pragma unroll
-        for (int j = 0; j < TW; ++j) b_cur[j] = Bs[fk * LD + wn * (BT / 2) + j * 32 + fr];
-#pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            if (kk + 1 < BK / 2) {
-#pragma unroll
-                for (int i = 0; i < TW; ++i) a_nxt[i] = As[((kk + 1) * 2 + fk) * LD + wm * (BT / 2) + i * 32 + fr];
-#pragma unroll
-                for (int j = 0; j < TW; ++j) b_nxt[j] = Bs[((kk + 1) * 2 + fk) * LD + wn * (BT / 2) + j * 32 + fr];
+        const float* As = lds + (kt & 1) * 2 * TILE;
+        const float* Bs = As + TILE;
+        if (ABL != 2 && kt + 1 < nk) {
+            float* An = lds + ((kt + 1) & 1) * 2 * TILE;
+            const int k1 = kbeg + (kt + 1) * BK;
+            la.store(An, k1, kend, p.a_transform, p.a_scale);
+            lb.store(An + TILE, k1, kend, 0, 0.f);
+            if (kt + 2 < nk) {
+                la.load(p.A, p.ak, k1 + BK, kend, p.a_vec);
+                lb.load(p.B, p.bk, k1 + BK, kend, p.b_vec);
             }
+        }
+        // K order inside a step: lane half fk of block j holds k = 8j + 4fk + i for the i-th MFMA (any permutation of
+        // k is legal as long as A and B use the same one), so a lane's 4 values are ONE 16-byte LDS read per tile.
+        const float* ap = As + (wm * (BT / 2) + fr) * LDK + 4 * fk;
+        const float* bp = Bs + (wn * (BT / 2) + fr) * LDK + 4 * fk;
+        f32x4 a4[2][TW], b4[2][TW];
 #pragma unroll
-            for (int i = 0; i < TW; ++i)
+        for (int i = 0; i < TW; ++i) a4[0][i] = *reinterpret_cast<const f32x4*>(ap + i * 32 * LDK);
+#pragma unroll
+        for (int j = 0; j < TW; ++j) b4[0][j] = *reinterpret_cast<const f32x4*>(bp + j * 32 * LDK);
+#pragma unroll
+        for (int jb = 0; jb < BK / 8; ++jb) {
+            const int cur = jb & 1;
+            if (jb + 1 < BK / 8) {  // fragments of the next 8-k block are in flight under this block's MFMAs
+#pragma unroll
+                for (int i = 0; i < TW; ++i)
+                    a4[cur ^ 1][i] = *reinterpret_cast<const f32x4*>(ap + i * 32 * LDK + (jb + 1) * 8);
 #pragma unroll
                 for (int j = 0; j < TW; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur[j], acc[i][j], 0, 0, 0);
+                    b4[cur ^ 1][j] = *reinterpret_cast<const f32x4*>(bp + j * 32 * LDK + (jb + 1) * 8);
+            }
 #pragma unroll
-            for (int i = 0; i < TW; ++i) a_cur[i] = a_nxt[i];
+            for (int e = 0; e < 4; ++e) {
+                if (ABL == 1) {
 #pragma unroll
-            for (int j = 0; j < TW; ++j) b_cur[j] = b_nxt[j];
+                    for (int i = 0; i < TW; ++i)
+#pragma unroll
+                        for (int j = 0; j < TW; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((float)(e + i + lane), (float)(e - j + lane),
+                                                                             acc[i][j], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TW; ++i)
+#pragma unroll
+                        for (int j = 0; j < TW; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[cur][i][e], b4[cur][j][e], acc[i][j], 0,
+                                                                             0, 0);
+                }
+            }
         }
         __syncthreads();
-        if (more) {
-            la.store(As, k_next, kend, p.a_transform, p.a_scale);
-            lb.store(Bs, k_next, kend, 0, 0.f);
-            __syncthreads();
-        }
     }
 
     // Epilogue. C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
@@ -324,9 +344,15 @@ bool axis_vec_ok(const cgn_axis& contig, const cgn_axis& other) {
     return true;
 }
 
+int g_ablate = 0;  // diagnostic builds only (tools/gemm_bench.py): 1 = no LDS reads, 2 = no staging in the loop
+
 template <int BT>
 void launch(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
-    if (a_kc && b_kc)
+    if (a_kc && b_kc && g_ablate == 1)
+        hipLaunchKernelGGL((gemm_kernel<BT, true, true, 1>), grid, dim3(NT), 0, s, p);
+    else if (a_kc && b_kc && g_ablate == 2)
+        hipLaunchKernelGGL((gemm_kernel<BT, true, true, 2>), grid, dim3(NT), 0, s, p);
+    else if (a_kc && b_kc)
         hipLaunchKernelGGL((gemm_kernel<BT, true, true>), grid, dim3(NT), 0, s, p);
     else if (a_kc && !b_kc)
         hipLaunchKernelGGL((gemm_kernel<BT, true, false>), grid, dim3(NT), 0, s, p);
@@ -369,8 +395,8 @@ int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out
             splitk = fit >= 2 ? (int)fit : 1;
         }
     }
-    int kps = cgn_cdiv(cgn_cdiv(d->K, splitk), BK) * BK;
-    if (kps < BK) kps = BK;
+    int kps = cgn_cdiv(cgn_cdiv(d->K, splitk), KROUND) * KROUND;
+    if (kps < KROUND) kps = KROUND;
     splitk = d->K > 0 ? cgn_cdiv(d->K, kps) : 1;
     *bt_out = bt; *splitk_out = splitk; *kps_out = kps;
     return CGN_OK;
@@ -379,6 +405,8 @@ int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out
 }  // namespace
 
 extern "C" int cgn_abi_version(void) { return 1; }
+
+extern "C" void cgn_debug_set_ablation(int v) { g_ablate = v; }
 
 extern "C" int cgn_gemm_plan(const cgn_gemm_desc* d, int32_t* tile, int32_t* splitk, int32_t* a_kcontig,
                              int32_t* b_kcontig) {

@@ -38,5 +38,10 @@ cases = [eval(a) for a in sys.argv[1:]] or [
     (1344, 512, 20000, "nn", 64, 5), (1344, 512, 20000, "nn", 128, 16), (1344, 512, 20000, "nn", 128, 24),
     (20000, 512, 1344, "tn", 128), (20000, 512, 1344, "tn", 128, 2),
 ]
-for c in cases:
-    bench(*c)
+from ldrs_amd.hip import _lib
+lib = _lib.load()
+for abl in (0, 1, 2, 0):
+    lib.cgn_debug_set_ablation(abl)
+    print("ablation", abl)
+    for c in cases:
+        bench(*c)
