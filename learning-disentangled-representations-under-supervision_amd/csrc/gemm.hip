@@ -16,18 +16,34 @@
 
 namespace {
 
+// Two-level axis, off(i) = (i / rpg) * gs + (i % rpg) * stride, evaluated WITHOUT a branch and without a hardware
+// division (both would sit between the global loads of the K loop, see TileLoader::load): i / rpg is a multiply by
+// magic = ceil(2^40 / rpg) and a shift, exact for i < 2^24 and rpg < 2^16 (checked on the host). A plain axis is the
+// same formula with rpg = 2^30, gs = 0 (i / rpg == 0 for every i < 2^30).
 struct Axis {
-    long stride, rpg, gs;
+    long stride, gs;
+    unsigned long magic;
+    int rpg;
 };
 
-// indices and group sizes fit 32 bits (checked on the host): 32-bit division keeps the inlined code small
 __device__ __forceinline__ long axis_off(const Axis& a, int i) {
-    if (a.rpg > 0) {
-        const int r = (int)a.rpg;
-        const int g = i / r;
-        return (long)g * a.gs + (long)(i - g * r) * a.stride;
+    const int g = (int)(((unsigned long)(unsigned)i * a.magic) >> 40);
+    return (long)g * a.gs + (long)(i - g * a.rpg) * a.stride;
+}
+
+Axis make_axis(const cgn_axis& c) {
+    Axis a;
+    a.stride = c.stride;
+    if (c.rpg > 0) {
+        a.rpg = (int)c.rpg;
+        a.gs = c.gs;
+        a.magic = ((1UL << 40) + (unsigned long)c.rpg - 1) / (unsigned long)c.rpg;
+    } else {
+        a.rpg = 1 << 30;
+        a.gs = 0;
+        a.magic = 1UL << 10;
     }
-    return (long)i * a.stride;
+    return a;
 }
 
 struct GemmParams {
@@ -52,6 +68,7 @@ struct GemmParams {
     float alpha, beta, a_scale, ep_inv_tau, ep_ce_scale;
 };
 
+constexpr int g_unroll_mult = 2;
 constexpr int KROUND = 32;  // split-K ranges are multiples of every BK in use
 constexpr int NT = 256;
 
@@ -75,7 +92,7 @@ __device__ __forceinline__ float apply_epilogue(const GemmParams& p, int row, in
 //   KC = true : memory is contiguous along k (row-major [rows][k]): thread = (row, k-quad), one float4 load per chunk
 //   KC = false: memory is contiguous along the row index ([k][rows]): thread = one row, lanes run along rows, scalar
 //               loads (a wave covers 64 consecutive rows = 256 contiguous bytes per k), 4 k per chunk
-template <int ROWS, bool KC, int BK>
+template <int ROWS, bool KC, int BK, int S, bool VEC, bool EXP>
 struct TileLoader {
     static constexpr int LDK = BK + 4;
     static constexpr int QUADS = ROWS * BK / 4;  // 4-k chunks per tile
@@ -84,12 +101,12 @@ struct TileLoader {
     static constexpr int KGROUPS = NT / ROWS;    // !KC: thread groups along k
     static_assert(KC || (BK / KGROUPS == 4 * PER), "k coverage");
 
-    f32x4 regs[PER];
+    f32x4 regs[S][PER];  // S register stages: S tiles of global loads in flight per thread
     long roff[KC ? PER : 1];
     bool rok[KC ? PER : 1];
     float rparam[KC ? PER : 1];
 
-    __device__ __forceinline__ void init(const Axis& ar, int r0, int rlimit, int transform, const float* row_param) {
+    __device__ __forceinline__ void init(const Axis& ar, int r0, int rlimit, const float* row_param) {
         const int tid = threadIdx.x;
         if constexpr (KC) {
             constexpr int QPR = BK / 4;   // quads per row
@@ -100,7 +117,7 @@ struct TileLoader {
                 const int row = r0 + r + i * RS;
                 rok[i] = row < rlimit;
                 roff[i] = rok[i] ? axis_off(ar, row) : 0;  // clamped: row 0 of the operand is always addressable
-                rparam[i] = (transform && rok[i]) ? row_param[row] : 0.f;
+                rparam[i] = EXP ? row_param[rok[i] ? row : 0] : 0.f;
             }
         } else {
             const int row = r0 + tid % ROWS;
@@ -110,22 +127,25 @@ struct TileLoader {
         }
     }
 
-    // Issue the global loads of the tile whose first k is k0 (k valid in [k0, kend)).
-    // Every load is UNCONDITIONAL on a clamped (always valid) address; nothing here consumes the loaded registers, so
-    // the loads stay in flight under the MFMAs of the current tile. Invalid elements are zeroed (and the optional
-    // exp transform applied) in store(), right before the LDS write. (A branch around a load, or a select right after
-    // it, makes hipcc wait vmcnt(0) on the spot and serialises the L2 round trips.)
-    __device__ __forceinline__ void load(const float* __restrict__ base, const Axis& ak, int k0, int kend, bool vec) {
+    // Issue the global loads of the tile whose first k is k0 (k valid in [k0, kend); kbeg = first k of this block).
+    // The code is BRANCH-FREE: every load is unconditional on a clamped (always valid) address and nothing here
+    // consumes the loaded registers, so S tiles of loads stay in flight under the MFMAs. Invalid elements are zeroed
+    // (and the optional exp transform applied) in store(), right before the LDS write. (Any branch around or between
+    // the loads — even a block-uniform one — makes hipcc's wait-count pass fall back to vmcnt(0) at the next use and
+    // serialises the L2 round trips; measured: 1.25 us per K step for a lone block.)
+    //   VEC: one 16-byte load per chunk. A quad may straddle kend only at the end of the contiguous axis, where the
+    //        host has checked that the padded row stride covers it; quads wholly beyond kend re-read the quad at kbeg.
+    __device__ __forceinline__ void load(int st, const float* __restrict__ base, const Axis& ak, int k0, int kbeg,
+                                         int kend) {
         const int tid = threadIdx.x;
         if constexpr (KC) {
             constexpr int QPR = BK / 4;
             const int q = tid % QPR;
             const int k = k0 + q * 4;
-            const bool interior = k0 + BK <= kend;  // block-uniform: every k of this step is valid
-            if (vec && interior) {
-                const long koff = axis_off(ak, k);
+            if constexpr (VEC) {
+                const long koff = axis_off(ak, k < kend ? k : kbeg);
 #pragma unroll
-                for (int i = 0; i < PER; ++i) regs[i] = *reinterpret_cast<const f32x4*>(base + roff[i] + koff);
+                for (int i = 0; i < PER; ++i) regs[st][i] = *reinterpret_cast<const f32x4*>(base + roff[i] + koff);
             } else {
                 long koff[4];
 #pragma unroll
@@ -135,24 +155,37 @@ struct TileLoader {
                     f32x4 v;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = base[roff[i] + koff[j]];
-                    regs[i] = v;
+                    regs[st][i] = v;
                 }
             }
         } else {
             const int kb = k0 + (tid / ROWS) * (4 * PER);  // wave-uniform
             const float* rb = base + roff[0];
+            // consecutive k: one magic division, then step (group, rest) by one with a select
+            const int kf = min(kb, kend - 1);
+            int g = (int)(((unsigned long)(unsigned)kf * ak.magic) >> 40);
+            int r = kf - g * ak.rpg;
+            int kk = kf;
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 f32x4 v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = rb[axis_off(ak, min(kb + 4 * i + j, kend - 1))];
-                regs[i] = v;
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = rb[(long)g * ak.gs + (long)r * ak.stride];
+                    const bool adv = kk < kend - 1;  // clamp at the last valid k
+                    kk += adv ? 1 : 0;
+                    r += adv ? 1 : 0;
+                    const bool wrap = r == ak.rpg;
+                    g += wrap ? 1 : 0;
+                    r = wrap ? 0 : r;
+                }
+                regs[st][i] = v;
             }
         }
     }
 
     // Mask/transform the staged registers and write them into the LDS image dst[ROWS][LDK].
-    __device__ __forceinline__ void store(float* __restrict__ dst, int k0, int kend, int transform, float scale) const {
+    __device__ __forceinline__ void store(int st, float* __restrict__ dst, int k0, int kend, float scale) const {
         const int tid = threadIdx.x;
         if constexpr (KC) {
             constexpr int QPR = BK / 4;
@@ -162,11 +195,11 @@ struct TileLoader {
             const int k = k0 + q * 4;
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
-                f32x4 v = regs[i];
+                f32x4 v = regs[st][i];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float x = v[j];
-                    if (transform == CGN_ATRANS_EXP) x = expf(x * scale - rparam[i]);
+                    if constexpr (EXP) x = expf(x * scale - rparam[i]);
                     v[j] = (rok[i] && k + j < kend) ? x : 0.f;
                 }
                 *reinterpret_cast<f32x4*>(dst + (r + i * RS) * LDK + q * 4) = v;
@@ -176,7 +209,7 @@ struct TileLoader {
             const int kl = (tid / ROWS) * (4 * PER);
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
-                f32x4 v = regs[i];
+                f32x4 v = regs[st][i];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = (rok[0] && k0 + kl + 4 * i + j < kend) ? v[j] : 0.f;
                 *reinterpret_cast<f32x4*>(dst + row * LDK + kl + 4 * i) = v;
@@ -194,9 +227,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return start + idx;
 }
 
-// BK: 16 for the 128-tile (3 blocks/CU by LDS and registers), 32 for the 64-tile (measured, tools/gemm_bench.py)
-template <int BT, bool A_KC, bool B_KC, int ABL = 0, int BK = (BT == 128 ? 16 : 32)>
-__global__ __launch_bounds__(NT) void gemm_kernel(const GemmParams p) {
+// BK: 16 for the 128-tile (3 blocks/CU by LDS and registers), 32 for the 64-tile (measured, tools/gemm_bench.py).
+// S: register stages = K tiles of global loads in flight per thread. Mid-size products of the CGN step have only
+// ~1 block per CU (260-700 tiles), so a wave must cover the L2/HBM round trip (~1-2 us) by itself: with one tile in
+// flight it stalls every K step (0.43 us of MFMA work per step).
+template <int BT, bool A_KC, bool B_KC, bool VEC, bool EXP, int S, int BK = (BT == 128 ? 16 : 32)>
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
     constexpr int TW = BT / 64;  // 32x32 accumulators per wave along each dim
     constexpr int LDK = BK + 4;  // LDS row stride (floats) of both operand images
     // One LDS array (both operands, two buffers): keeps every carve offset explicit and 16-byte aligned.
@@ -217,92 +253,103 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmParams p) {
     const int wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    TileLoader<BT, A_KC, BK> la;
-    TileLoader<BT, B_KC, BK> lb;
-    la.init(p.am, m0, p.M, p.a_transform, p.a_row_param);
-    lb.init(p.bn, n0, p.N, 0, nullptr);
+    TileLoader<BT, A_KC, BK, S, VEC, EXP> la;
+    TileLoader<BT, B_KC, BK, S, VEC, false> lb;
+    la.init(p.am, m0, p.M, p.a_row_param);
+    lb.init(p.bn, n0, p.N, nullptr);
 
-    f32x16 acc[TW][TW];
+    // the 64-tile has one 32x32 output per wave: two accumulator chains (even / odd k) halve the dependent-MFMA chain
+    constexpr int NC = (TW == 1) ? 2 : 1;
+    f32x16 acc[NC][TW][TW];
 #pragma unroll
     for (int i = 0; i < TW; ++i)
 #pragma unroll
         for (int j = 0; j < TW; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c][i][j][r] = 0.f;
 
-    // Pipeline (one barrier per K step, global loads a full step ahead, LDS double-buffered):
-    //   step kt:  write tile kt+1 (registers, loaded during step kt-1) into buf[(kt+1)&1]
-    //             issue the global loads of tile kt+2 into the staging registers
+    // Pipeline (one barrier per K step, LDS double-buffered, S tiles of global loads in flight):
+    //   tile j lives in register stage j % S from its load until it is written to LDS buffer j & 1
+    //   step kt:  write tile kt+1 (loaded during step kt-S) into buf[(kt+1)&1]
+    //             issue the global loads of tile kt+1+S into the stage just freed
     //             MFMAs on buf[kt&1]
     //             barrier
+    // The loop is unrolled by U = lcm(S, 2) so that stage and buffer indices are compile-time constants.
+    // Loads and LDS writes past the last tile are not skipped (that would need a branch, see TileLoader::load): they
+    // re-read the block's first quads (L1/L2 hits) and write a buffer nobody reads again.
     const int nk = (kend - kbeg + BK - 1) / BK;
     if (nk > 0) {
-        la.load(p.A, p.ak, kbeg, kend, p.a_vec);
-        lb.load(p.B, p.bk, kbeg, kend, p.b_vec);
-        la.store(lds, kbeg, kend, p.a_transform, p.a_scale);
-        lb.store(lds + TILE, kbeg, kend, 0, 0.f);
-        if (nk > 1) {
-            la.load(p.A, p.ak, kbeg + BK, kend, p.a_vec);
-            lb.load(p.B, p.bk, kbeg + BK, kend, p.b_vec);
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            la.load(j, p.A, p.ak, kbeg + j * BK, kbeg, kend);
+            lb.load(j, p.B, p.bk, kbeg + j * BK, kbeg, kend);
         }
+        la.store(0, lds, kbeg, kend, p.a_scale);
+        lb.store(0, lds + TILE, kbeg, kend, 0.f);
+        la.load(0, p.A, p.ak, kbeg + S * BK, kbeg, kend);
+        lb.load(0, p.B, p.bk, kbeg + S * BK, kbeg, kend);
     }
     __syncthreads();
 
     const int fr = lane & 31;  // fragment row/col
     const int fk = lane >> 5;  // k-slice within the 32x32x2 step
-    for (int kt = 0; kt < nk; ++kt) {
-        const float* As = lds + (kt & 1) * 2 * TILE;
-        const float* Bs = As + TILE;
-        if (ABL != 2 && kt + 1 < nk) {
-            float* An = lds + ((kt + 1) & 1) * 2 * TILE;
-            const int k1 = kbeg + (kt + 1) * BK;
-            la.store(An, k1, kend, p.a_transform, p.a_scale);
-            lb.store(An + TILE, k1, kend, 0, 0.f);
-            if (kt + 2 < nk) {
-                la.load(p.A, p.ak, k1 + BK, kend, p.a_vec);
-                lb.load(p.B, p.bk, k1 + BK, kend, p.b_vec);
+    // U steps per trip, a multiple of lcm(S, 2): hipcc's wait-count pass is exact inside the unrolled body but
+    // waits for ALL outstanding loads at the first LDS store after the loop header, so make trips long.
+    constexpr int U = g_unroll_mult * ((S % 2 == 0) ? S : 2 * S);
+    for (int kt0 = 0; kt0 < nk; kt0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kt = kt0 + u;
+            if (kt >= nk) break;  // block-uniform
+            const float* As = lds + (u & 1) * 2 * TILE;
+            const float* Bs = As + TILE;
+            {
+                const int st = (u + 1) % S;
+                float* An = lds + ((u + 1) & 1) * 2 * TILE;
+                const int k1 = kbeg + (kt + 1) * BK;
+                la.store(st, An, k1, kend, p.a_scale);
+                lb.store(st, An + TILE, k1, kend, 0.f);
+                la.load(st, p.A, p.ak, k1 + S * BK, kbeg, kend);
+                lb.load(st, p.B, p.bk, k1 + S * BK, kbeg, kend);
             }
-        }
-        // K order inside a step: lane half fk of block j holds k = 8j + 4fk + i for the i-th MFMA (any permutation of
-        // k is legal as long as A and B use the same one), so a lane's 4 values are ONE 16-byte LDS read per tile.
-        const float* ap = As + (wm * (BT / 2) + fr) * LDK + 4 * fk;
-        const float* bp = Bs + (wn * (BT / 2) + fr) * LDK + 4 * fk;
-        f32x4 a4[2][TW], b4[2][TW];
+            // K order inside a step: lane half fk of block j holds k = 8j + 4fk + i for the i-th MFMA (any permutation
+            // of k is legal as long as A and B use the same one), so a lane's 4 values are ONE 16-byte LDS read per tile.
+            const float* ap = As + (wm * (BT / 2) + fr) * LDK + 4 * fk;
+            const float* bp = Bs + (wn * (BT / 2) + fr) * LDK + 4 * fk;
+            f32x4 a4[2][TW], b4[2][TW];
 #pragma unroll
-        for (int i = 0; i < TW; ++i) a4[0][i] = *reinterpret_cast<const f32x4*>(ap + i * 32 * LDK);
+            for (int i = 0; i < TW; ++i) a4[0][i] = *reinterpret_cast<const f32x4*>(ap + i * 32 * LDK);
 #pragma unroll
-        for (int j = 0; j < TW; ++j) b4[0][j] = *reinterpret_cast<const f32x4*>(bp + j * 32 * LDK);
+            for (int j = 0; j < TW; ++j) b4[0][j] = *reinterpret_cast<const f32x4*>(bp + j * 32 * LDK);
 #pragma unroll
-        for (int jb = 0; jb < BK / 8; ++jb) {
-            const int cur = jb & 1;
-            if (jb + 1 < BK / 8) {  // fragments of the next 8-k block are in flight under this block's MFMAs
-#pragma unroll
-                for (int i = 0; i < TW; ++i)
-                    a4[cur ^ 1][i] = *reinterpret_cast<const f32x4*>(ap + i * 32 * LDK + (jb + 1) * 8);
-#pragma unroll
-                for (int j = 0; j < TW; ++j)
-                    b4[cur ^ 1][j] = *reinterpret_cast<const f32x4*>(bp + j * 32 * LDK + (jb + 1) * 8);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (ABL == 1) {
+            for (int jb = 0; jb < BK / 8; ++jb) {
+                const int cur = jb & 1;
+                if (jb + 1 < BK / 8) {  // fragments of the next 8-k block are in flight under this block's MFMAs
 #pragma unroll
                     for (int i = 0; i < TW; ++i)
+                        a4[cur ^ 1][i] = *reinterpret_cast<const f32x4*>(ap + i * 32 * LDK + (jb + 1) * 8);
 #pragma unroll
-                        for (int j = 0; j < TW; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((float)(e + i + lane), (float)(e - j + lane),
-                                                                             acc[i][j], 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < TW; ++i)
-#pragma unroll
-                        for (int j = 0; j < TW; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[cur][i][e], b4[cur][j][e], acc[i][j], 0,
-                                                                             0, 0);
+                    for (int j = 0; j < TW; ++j)
+                        b4[cur ^ 1][j] = *reinterpret_cast<const f32x4*>(bp + j * 32 * LDK + (jb + 1) * 8);
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TW; ++i)
+#pragma unroll
+                        for (int j = 0; j < TW; ++j)
+                            acc[e % NC][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[cur][i][e], b4[cur][j][e], acc[e % NC][i][j], 0,
+                                                                             0, 0);
             }
+            __syncthreads();
         }
-        __syncthreads();
+    }
+
+    if constexpr (NC == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][0][r] += acc[1][0][0][r];
     }
 
     // Epilogue. C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
@@ -317,9 +364,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmParams p) {
                 const int row = m0 + wm * (BT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
                 if (row >= p.M) continue;
                 if (p.splitk > 1) {
-                    p.ws[((long)blockIdx.y * p.M + row) * p.N + col] = acc[i][j][r];
+                    p.ws[((long)blockIdx.y * p.M + row) * p.N + col] = acc[0][i][j][r];
                 } else {
-                    p.C[(long)row * p.ldc + col] = apply_epilogue(p, row, col, acc[i][j][r]);
+                    p.C[(long)row * p.ldc + col] = apply_epilogue(p, row, col, acc[0][i][j][r]);
                 }
             }
         }
@@ -336,30 +383,58 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
     }
 }
 
-bool axis_vec_ok(const cgn_axis& contig, const cgn_axis& other) {
+// 16-byte loads along `contig` (extent n): aligned strides, and a quad that straddles the end of the axis must stay
+// inside memory the caller owns: n % 4 == 0, or plain rows whose padded stride covers the rounded-up extent.
+bool axis_vec_ok(const cgn_axis& contig, const cgn_axis& other, int n) {
     if (contig.stride != 1) return false;
+    if (n % 4 != 0 && !(contig.rpg == 0 && other.rpg == 0 && other.stride >= (n + 3) / 4 * 4)) return false;
     if (contig.rpg != 0 && (contig.rpg % 4 != 0 || contig.gs % 4 != 0)) return false;
     if (other.stride % 4 != 0) return false;
     if (other.rpg != 0 && other.gs % 4 != 0) return false;
     return true;
 }
 
-int g_ablate = 0;  // diagnostic builds only (tools/gemm_bench.py): 1 = no LDS reads, 2 = no staging in the loop
+int g_stages = 0;  // 0 = default; tools/gemm_bench.py overrides it through cgn_debug_set_stages
+
+template <int BT, int S, bool VEC, bool EXP>
+void launch_v(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
+    if constexpr (EXP) {  // the exp transform needs a k-contiguous A (checked by the caller)
+        if (b_kc)
+            hipLaunchKernelGGL((gemm_kernel<BT, true, true, VEC, true, S>), grid, dim3(NT), 0, s, p);
+        else
+            hipLaunchKernelGGL((gemm_kernel<BT, true, false, VEC, true, S>), grid, dim3(NT), 0, s, p);
+    } else {
+        if (a_kc && b_kc)
+            hipLaunchKernelGGL((gemm_kernel<BT, true, true, VEC, false, S>), grid, dim3(NT), 0, s, p);
+        else if (a_kc && !b_kc)
+            hipLaunchKernelGGL((gemm_kernel<BT, true, false, VEC, false, S>), grid, dim3(NT), 0, s, p);
+        else if (!a_kc && b_kc)
+            hipLaunchKernelGGL((gemm_kernel<BT, false, true, VEC, false, S>), grid, dim3(NT), 0, s, p);
+        else
+            hipLaunchKernelGGL((gemm_kernel<BT, false, false, VEC, false, S>), grid, dim3(NT), 0, s, p);
+    }
+}
 
 template <int BT>
 void launch(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
-    if (a_kc && b_kc && g_ablate == 1)
-        hipLaunchKernelGGL((gemm_kernel<BT, true, true, 1>), grid, dim3(NT), 0, s, p);
-    else if (a_kc && b_kc && g_ablate == 2)
-        hipLaunchKernelGGL((gemm_kernel<BT, true, true, 2>), grid, dim3(NT), 0, s, p);
-    else if (a_kc && b_kc)
-        hipLaunchKernelGGL((gemm_kernel<BT, true, true>), grid, dim3(NT), 0, s, p);
-    else if (a_kc && !b_kc)
-        hipLaunchKernelGGL((gemm_kernel<BT, true, false>), grid, dim3(NT), 0, s, p);
-    else if (!a_kc && b_kc)
-        hipLaunchKernelGGL((gemm_kernel<BT, false, true>), grid, dim3(NT), 0, s, p);
-    else
-        hipLaunchKernelGGL((gemm_kernel<BT, false, false>), grid, dim3(NT), 0, s, p);
+    // VEC kernels: every k-contiguous operand is read with 16-byte loads; otherwise the all-scalar variant
+    const bool vec = (!a_kc || p.a_vec) && (!b_kc || p.b_vec);
+    const bool ex = p.a_transform == CGN_ATRANS_EXP;
+    if (!vec) {
+        if (ex) launch_v<BT, 2, false, true>(p, a_kc, b_kc, grid, s);
+        else launch_v<BT, 2, false, false>(p, a_kc, b_kc, grid, s);
+        return;
+    }
+    if (ex) {
+        launch_v<BT, 2, true, true>(p, a_kc, b_kc, grid, s);
+        return;
+    }
+    switch (g_stages) {
+        case 1: launch_v<BT, 1, true, false>(p, a_kc, b_kc, grid, s); break;
+        case 3: launch_v<BT, 3, true, false>(p, a_kc, b_kc, grid, s); break;
+        case 4: launch_v<BT, 4, true, false>(p, a_kc, b_kc, grid, s); break;
+        default: launch_v<BT, 2, true, false>(p, a_kc, b_kc, grid, s); break;
+    }
 }
 
 // Tile / split-K heuristic: MI355X has 256 CUs and this kernel fits ~3-4 blocks per CU; aim for >= ~512 blocks.
@@ -378,12 +453,18 @@ int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out
     }
     const long tiles = bt == 128 ? t128 : t64;
     if (splitk <= 0) {
-        const int min_k = bt == 128 ? 512 : 256;  // keep at least this much K per split
-        long want = (1024 + tiles - 1) / tiles;
+        // Measured (tools/gemm_bench.py sweeps): with >= 2 blocks per CU a split only adds slab traffic; below that,
+        // splitting K until ~1024 blocks exist wins as long as every split keeps a few K steps. Products with a
+        // handful of tiles (e2mu/e2logvar, d[z,c], the text-CNN windows) are pure latency chains of K/BK dependent
+        // steps on one CU each: split them hard, whatever their FLOP count.
+        const bool few = tiles < 64;
+        const int min_k = few ? 128 : (bt == 128 ? 512 : 256);
+        long want = tiles >= 512 ? 1 : (1024 + tiles - 1) / tiles;
+        if (few && want > 16) want = 16;
         const long max_by_k = d->K / min_k;
         if (want > max_by_k) want = max_by_k;
-        // a split costs a slab round trip plus a reduce launch (~5 us): skip it for products under ~0.25 GFLOP
-        if ((double)d->M * d->N * d->K < 1.25e8) want = 1;
+        // a split costs a slab round trip plus a reduce launch (~5 us): skip it for small many-tile products
+        if (!few && (double)d->M * d->N * d->K < 1.25e8) want = 1;
         if (want < 1) want = 1;
         splitk = (int)want;
     }
@@ -406,7 +487,7 @@ int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out
 
 extern "C" int cgn_abi_version(void) { return 1; }
 
-extern "C" void cgn_debug_set_ablation(int v) { g_ablate = v; }
+extern "C" void cgn_debug_set_stages(int v) { g_stages = v; }
 
 extern "C" int cgn_gemm_plan(const cgn_gemm_desc* d, int32_t* tile, int32_t* splitk, int32_t* a_kcontig,
                              int32_t* b_kcontig) {
@@ -427,8 +508,12 @@ extern "C" int cgn_gemm_f32(void* stream, const cgn_gemm_desc* d) {
     if (d->M == 0 || d->N == 0) return CGN_OK;
     CGN_CHECK_ARG(d->A && d->B && d->C);
     CGN_CHECK_ARG(d->ldc >= d->N);
-    CGN_CHECK_ARG(d->a_m.rpg < (1L << 31) && d->a_k.rpg < (1L << 31) && d->b_k.rpg < (1L << 31) &&
-                  d->b_n.rpg < (1L << 31));
+    // index ranges of the magic-number division in axis_off()
+    CGN_CHECK_ARG(d->M < (1 << 30) && d->N < (1 << 30) && d->K < (1 << 30));
+    CGN_CHECK_ARG(d->a_m.rpg >= 0 && d->a_k.rpg >= 0 && d->b_k.rpg >= 0 && d->b_n.rpg >= 0);
+    CGN_CHECK_ARG(d->a_m.rpg < (1 << 16) && d->a_k.rpg < (1 << 16) && d->b_k.rpg < (1 << 16) && d->b_n.rpg < (1 << 16));
+    CGN_CHECK_ARG((d->a_m.rpg == 0 || d->M < (1 << 24)) && (d->b_n.rpg == 0 || d->N < (1 << 24)) &&
+                  ((d->a_k.rpg == 0 && d->b_k.rpg == 0) || d->K < (1 << 24)));
     CGN_CHECK_ARG(d->a_transform == CGN_ATRANS_NONE || (d->a_transform == CGN_ATRANS_EXP && d->a_row_param));
     CGN_CHECK_ARG(d->epilogue == CGN_EPI_LINEAR || d->epilogue == CGN_EPI_SOFTMAX_BWD);
     if (d->epilogue == CGN_EPI_SOFTMAX_BWD)
@@ -444,16 +529,13 @@ extern "C" int cgn_gemm_f32(void* stream, const cgn_gemm_desc* d) {
     p.bias0 = d->bias0; p.bias1 = d->bias1; p.a_row_param = d->a_row_param;
     p.ep_logits = d->ep_logits; p.ep_lse = d->ep_lse; p.ep_rowdot = d->ep_rowdot; p.ep_target = d->ep_target;
     p.ldc = d->ldc; p.ep_ld = d->ep_ld;
-    p.am = {d->a_m.stride, d->a_m.rpg, d->a_m.gs};
-    p.ak = {d->a_k.stride, d->a_k.rpg, d->a_k.gs};
-    p.bk = {d->b_k.stride, d->b_k.rpg, d->b_k.gs};
-    p.bn = {d->b_n.stride, d->b_n.rpg, d->b_n.gs};
+    p.am = make_axis(d->a_m); p.ak = make_axis(d->a_k); p.bk = make_axis(d->b_k); p.bn = make_axis(d->b_n);
     p.M = d->M; p.N = d->N; p.K = d->K;
     p.a_transform = d->a_transform; p.epilogue = d->epilogue;
     p.alpha = d->alpha; p.beta = d->beta; p.a_scale = d->a_scale;
     p.ep_inv_tau = d->ep_inv_tau; p.ep_ce_scale = d->ep_ce_scale;
-    p.a_vec = ((uintptr_t)d->A % 16 == 0) && (a_kc ? axis_vec_ok(d->a_k, d->a_m) : axis_vec_ok(d->a_m, d->a_k));
-    p.b_vec = ((uintptr_t)d->B % 16 == 0) && (b_kc ? axis_vec_ok(d->b_k, d->b_n) : axis_vec_ok(d->b_n, d->b_k));
+    p.a_vec = ((uintptr_t)d->A % 16 == 0) && a_kc && axis_vec_ok(d->a_k, d->a_m, d->K);
+    p.b_vec = ((uintptr_t)d->B % 16 == 0) && b_kc && axis_vec_ok(d->b_k, d->b_n, d->K);
 
     int bt, splitk, kps;
     {

@@ -138,8 +138,12 @@ def test_gemm_planner_host_only():
     assert rc == 0 and tile == 128 and sk == 1 and (ak, bk) == (1, 1)
     rc, (tile, sk, ak, bk) = _plan(1344, 512, 20000, nt=False)  # dH = dlogits . W_fc : long K, few tiles => split-K
     assert rc == 0 and sk > 1 and (ak, bk) == (1, 0)
-    rc, (tile, sk, _, _) = _plan(64, 128, 1024)  # e2mu/e2logvar: small
+    rc, (tile, sk, _, _) = _plan(64, 128, 1024)  # e2mu/e2logvar: 2 tiles, a latency chain => split hard
+    assert rc == 0 and tile == 64 and sk == 8
+    rc, (tile, sk, _, _) = _plan(1344, 2048, 512)  # LSTM input projection: 672 tiles already fill the GPU
     assert rc == 0 and tile == 64 and sk == 1
+    rc, (tile, sk, _, _) = _plan(64, 64, 64)  # nothing to split
+    assert rc == 0 and sk == 1
     rc, (_, sk, _, _) = _plan(1344, 512, 20000, nt=False, workspace=None)  # no workspace => no split, still valid
     assert rc == 0 and sk == 1
     rc, _ = _plan(1344, 512, 20000, nt=False, workspace=None, force_splitk=8)

@@ -40,8 +40,8 @@ cases = [eval(a) for a in sys.argv[1:]] or [
 ]
 from ldrs_amd.hip import _lib
 lib = _lib.load()
-for abl in (0, 1, 2, 0):
-    lib.cgn_debug_set_ablation(abl)
-    print("ablation", abl)
+for st in [int(x) for x in os.environ.get('GEMM_STAGES', '2').split(',')]:
+    lib.cgn_debug_set_stages(st)
+    print("stages", st)
     for c in cases:
         bench(*c)
