@@ -81,6 +81,10 @@ typedef struct cgn_gemm_desc {
     float ep_inv_tau, ep_ce_scale;
     int32_t force_tile;   /* 0 = heuristic, 64 or 128 = force that square tile (tests/tuning) */
     int32_t force_splitk; /* 0 = heuristic */
+    /* Optional DEVICE scalars {inv_tau, ce_scale} (NULL = use the immediates above). When given, a_scale (exp
+     * transform) and ep_inv_tau read [0] and ep_ce_scale reads [1] at run time, so a captured hipGraph of the step
+     * can be replayed while the temperature schedule (utils/functional.py:35-42) advances. */
+    const float* dyn_scalars;
 } cgn_gemm_desc;
 
 int cgn_gemm_f32(void* stream, const cgn_gemm_desc* desc /* host */);
@@ -97,7 +101,8 @@ int cgn_gemm_plan(const cgn_gemm_desc* desc /* host */, int32_t* tile, int32_t* 
  * logits is [M, V] with row stride ld.
  * ---------------------------------------------------------------------------------------------------------- */
 int cgn_softmax_nll_fwd_f32(void* stream, const float* logits, int64_t ld, const int64_t* target, int32_t M, int32_t V,
-                            float inv_tau, float* lse, float* nll, float* loss);
+                            float inv_tau, const float* dyn_inv_tau /* device, nullable: overrides inv_tau */,
+                            float* lse, float* nll, float* loss);
 
 /* ------------------------------------------------------------------------------------------------------------
  * LSTM recurrence (nn.LSTM at model/encoder.py:17-21,40 and model/generator.py:17-20,58). The input projections
@@ -201,7 +206,8 @@ int cgn_reparam_kld_fwd_f32(void* stream, const float* mulv, const float* eps, c
                             int32_t C, float* zc, float* stdv, float* kld);
 /* dmulv = d/d[mu|logvar] of (g·z + kld_weight*B*kld), g = dL/dz (nullable, row stride ldg), kld_weight = kld_coef/B. */
 int cgn_reparam_kld_bwd_f32(void* stream, const float* mulv, const float* eps, const float* g, int64_t ldg,
-                            float kld_weight, int32_t B, int32_t Z, float* dmulv);
+                            float kld_weight, const float* dyn_kld_weight /* device, nullable: overrides kld_weight */,
+                            int32_t B, int32_t Z, float* dmulv);
 /* out[c] = beta*out[c] + sum_r x[r,c] (bias gradients); workspace >= 64*C floats. */
 int cgn_colsum_f32(void* stream, const float* x, int64_t ld, int32_t R, int32_t C, float beta, float* out,
                    float* workspace, int64_t workspace_bytes);
@@ -213,7 +219,10 @@ int cgn_rowdot_f32(void* stream, const float* a, int64_t lda, const float* b, in
 /* torch.optim.Adam defaults (model/cgn.py:267,1046-1047) over a flat parameter arena; g is read as g*grad_scale
  * (1/world_size after a sum all-reduce). step >= 1 is the step count AFTER this update. */
 int cgn_adam_f32(void* stream, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                 float beta2, float eps, int32_t step, float grad_scale);
+                 float beta2, float eps, int32_t step, const int32_t* dyn_step /* device, nullable: overrides step */,
+                 float grad_scale);
+/* counter[0] += 1 on the stream: advances a device-resident Adam step count inside a captured hipGraph. */
+int cgn_incr_i32(void* stream, int32_t* counter);
 /* 2-class head (discriminator_sentiment.py:76-77 + losses of cgn.py:167-170,306,318-334,1118):
  * logits = (feat*mask)·Wᵀ + b; stats = {mean CE(y), mean entropy}; p1 = softmax[:,1];
  * dlogits = d(w_ce*CE + w_ent*entropy)/dlogits. mask, y, p1, dlogits, stats nullable. */

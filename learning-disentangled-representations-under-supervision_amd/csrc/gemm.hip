@@ -58,6 +58,7 @@ struct GemmParams {
     const float* ep_rowdot;
     const int64_t* ep_target;
     float* ws;
+    const float* dyn;  // optional device scalars {inv_tau, ce_scale}: override a_scale/ep_inv_tau and ep_ce_scale
     long ldc, ep_ld;
     Axis am, ak, bk, bn;
     int M, N, K;
@@ -74,9 +75,11 @@ constexpr int NT = 256;
 
 __device__ __forceinline__ float apply_epilogue(const GemmParams& p, int row, int col, float acc) {
     if (p.epilogue == CGN_EPI_SOFTMAX_BWD) {
-        const float pr = expf(p.ep_logits[(long)row * p.ep_ld + col] * p.ep_inv_tau - p.ep_lse[row]);
+        const float inv_tau = p.dyn ? p.dyn[0] : p.ep_inv_tau;
+        const float ce_scale = p.dyn ? p.dyn[1] : p.ep_ce_scale;
+        const float pr = expf(p.ep_logits[(long)row * p.ep_ld + col] * inv_tau - p.ep_lse[row]);
         const float onehot = (p.ep_target[row] == (int64_t)col) ? 1.f : 0.f;
-        return pr * (acc - p.ep_rowdot[row]) * p.ep_inv_tau + p.ep_ce_scale * (pr - onehot);
+        return pr * (acc - p.ep_rowdot[row]) * inv_tau + ce_scale * (pr - onehot);
     }
     float v = p.alpha * acc;
     if (p.bias0) v += p.bias0[col];
@@ -252,6 +255,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    const float a_scale = (EXP && p.dyn) ? p.dyn[0] : p.a_scale;
 
     TileLoader<BT, A_KC, BK, S, VEC, EXP> la;
     TileLoader<BT, B_KC, BK, S, VEC, false> lb;
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
             la.load(j, p.A, p.ak, kbeg + j * BK, kbeg, kend);
             lb.load(j, p.B, p.bk, kbeg + j * BK, kbeg, kend);
         }
-        la.store(0, lds, kbeg, kend, p.a_scale);
+        la.store(0, lds, kbeg, kend, a_scale);
         lb.store(0, lds + TILE, kbeg, kend, 0.f);
         la.load(0, p.A, p.ak, kbeg + S * BK, kbeg, kend);
         lb.load(0, p.B, p.bk, kbeg + S * BK, kbeg, kend);
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
                 const int st = (u + 1) % S;
                 float* An = lds + ((u + 1) & 1) * 2 * TILE;
                 const int k1 = kbeg + (kt + 1) * BK;
-                la.store(st, An, k1, kend, p.a_scale);
+                la.store(st, An, k1, kend, a_scale);
                 lb.store(st, An + TILE, k1, kend, 0.f);
                 la.load(st, p.A, p.ak, k1 + S * BK, kbeg, kend);
                 lb.load(st, p.B, p.bk, k1 + S * BK, kbeg, kend);
@@ -485,7 +489,7 @@ int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out
 
 }  // namespace
 
-extern "C" int cgn_abi_version(void) { return 1; }
+extern "C" int cgn_abi_version(void) { return 2; }
 
 extern "C" void cgn_debug_set_stages(int v) { g_stages = v; }
 
@@ -548,6 +552,7 @@ extern "C" int cgn_gemm_f32(void* stream, const cgn_gemm_desc* d) {
     p.k_per_split = kps;
     p.splitk = splitk;
     p.ws = d->workspace;
+    p.dyn = d->dyn_scalars;
 
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)tiles, (unsigned)splitk);

@@ -135,8 +135,10 @@ __global__ __launch_bounds__(256) void reparam_kld_fwd_kernel(const float* __res
 // d(mulv) given g = dL/dz (row stride ldg, nullable) and the KLD term weight w = kld_coef / B:
 //   dmu = g + w*mu ; dlogvar = g*eps*0.5*std + w*0.5*(e^logvar - 1)
 __global__ __launch_bounds__(PW_NT) void reparam_kld_bwd_kernel(const float* __restrict__ mulv, const float* __restrict__ eps,
-                                                                const float* __restrict__ g, long ldg, float w, int B,
-                                                                int Z, float* __restrict__ dmulv) {
+                                                                const float* __restrict__ g, long ldg, float w_imm,
+                                                                const float* __restrict__ dyn_w, int B, int Z,
+                                                                float* __restrict__ dmulv) {
+    const float w = dyn_w ? dyn_w[0] : w_imm;
     const int total = B * Z;
     for (int i = blockIdx.x * PW_NT + threadIdx.x; i < total; i += gridDim.x * PW_NT) {
         const int b = i / Z, k = i % Z;
@@ -195,7 +197,12 @@ __global__ __launch_bounds__(PW_NT) void rowdot_kernel(const float* __restrict__
 __global__ __launch_bounds__(PW_NT) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                      float* __restrict__ m, float* __restrict__ v, long n, float lr,
                                                      float b1, float b2, float eps, float bc1, float bc2_sqrt,
-                                                     float grad_scale) {
+                                                     const int* __restrict__ dyn_step, float grad_scale) {
+    if (dyn_step) {  // device-resident step count: same double-precision bias corrections as the host path
+        const double t = (double)dyn_step[0];
+        bc1 = (float)(1.0 - pow((double)b1, t));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+    }
     const float step_size = lr / bc1;
     for (long i = (long)blockIdx.x * PW_NT + threadIdx.x; i < n; i += (long)gridDim.x * PW_NT) {
         const float gi = g[i] * grad_scale;
@@ -207,6 +214,8 @@ __global__ __launch_bounds__(PW_NT) void adam_kernel(float* __restrict__ p, cons
         p[i] = p[i] - step_size * (mi / denom);
     }
 }
+
+__global__ void incr_kernel(int* counter) { counter[0] += 1; }
 
 // ---- 2-class discriminator head: fc1 + CE / entropy losses and their gradient wrt the logits ---------------------
 // (model/discriminator_sentiment.py:76-77, model/cgn.py:167-170, :306, :318-334, :1118)
@@ -450,11 +459,12 @@ extern "C" int cgn_reparam_kld_fwd_f32(void* stream, const float* mulv, const fl
 }
 
 extern "C" int cgn_reparam_kld_bwd_f32(void* stream, const float* mulv, const float* eps, const float* g, int64_t ldg,
-                                       float kld_weight, int32_t B, int32_t Z, float* dmulv) {
+                                       float kld_weight, const float* dyn_kld_weight, int32_t B, int32_t Z,
+                                       float* dmulv) {
     CGN_CHECK_ARG(B > 0 && Z > 0);
     CGN_CHECK_ARG(mulv && eps && dmulv && (!g || ldg >= Z));
     hipLaunchKernelGGL(reparam_kld_bwd_kernel, dim3(pw_blocks((long)B * Z)), dim3(PW_NT), 0, S_(stream), mulv, eps, g,
-                       (long)ldg, kld_weight, B, Z, dmulv);
+                       (long)ldg, kld_weight, dyn_kld_weight, B, Z, dmulv);
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }
@@ -498,15 +508,23 @@ extern "C" int cgn_rowdot_f32(void* stream, const float* a, int64_t lda, const f
 }
 
 extern "C" int cgn_adam_f32(void* stream, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                            float beta2, float eps, int32_t step, float grad_scale) {
-    CGN_CHECK_ARG(n >= 0 && step >= 1);
+                            float beta2, float eps, int32_t step, const int32_t* dyn_step, float grad_scale) {
+    CGN_CHECK_ARG(n >= 0 && (dyn_step || step >= 1));
     if (n == 0) return CGN_OK;
     CGN_CHECK_ARG(p && g && m && v);
-    // bias corrections in double on the host, as torch does for python-scalar steps
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    // bias corrections in double on the host, as torch does for python-scalar steps; with a device-resident step
+    // count (graph replay) the kernel forms them itself, also in double
+    const double bc1 = dyn_step ? 0.0 : 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = dyn_step ? 0.0 : 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(pw_blocks(n, PW_NT, 8192)), dim3(PW_NT), 0, S_(stream), p, g, m, v, (long)n, lr,
-                       beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+                       beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), dyn_step, grad_scale);
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}
+
+extern "C" int cgn_incr_i32(void* stream, int32_t* counter) {
+    CGN_CHECK_ARG(counter != nullptr);
+    hipLaunchKernelGGL(incr_kernel, dim3(1), dim3(1), 0, S_(stream), counter);
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }

@@ -17,8 +17,9 @@ __device__ __forceinline__ void online_update(float& m, float& s, float x) {
 
 __global__ __launch_bounds__(SM_NT) void softmax_nll_fwd_kernel(const float* __restrict__ logits, long ld,
                                                                 const int64_t* __restrict__ target, int V,
-                                                                float inv_tau, float* __restrict__ lse,
-                                                                float* __restrict__ nll) {
+                                                                float inv_tau_imm, const float* __restrict__ dyn,
+                                                                float* __restrict__ lse, float* __restrict__ nll) {
+    const float inv_tau = dyn ? dyn[0] : inv_tau_imm;
     __shared__ float red_m[SM_NT / 64];
     __shared__ float red_s[SM_NT / 64];
     const int row = blockIdx.x;
@@ -88,13 +89,14 @@ __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, 
 }  // namespace
 
 extern "C" int cgn_softmax_nll_fwd_f32(void* stream, const float* logits, int64_t ld, const int64_t* target, int32_t M,
-                                       int32_t V, float inv_tau, float* lse, float* nll, float* loss) {
+                                       int32_t V, float inv_tau, const float* dyn_inv_tau, float* lse, float* nll,
+                                       float* loss) {
     CGN_CHECK_ARG(M >= 0 && V > 0 && ld >= V);
     if (M == 0) return CGN_OK;
     CGN_CHECK_ARG(logits && target && lse && nll && loss);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(softmax_nll_fwd_kernel, dim3(M), dim3(SM_NT), 0, s, logits, (long)ld, target, V, inv_tau, lse,
-                       nll);
+    hipLaunchKernelGGL(softmax_nll_fwd_kernel, dim3(M), dim3(SM_NT), 0, s, logits, (long)ld, target, V, inv_tau,
+                       dyn_inv_tau, lse, nll);
     CGN_LAUNCH_CHECK();
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, nll, M, 1.0f / (float)M, loss);
     CGN_LAUNCH_CHECK();

@@ -43,6 +43,7 @@ class GemmDesc(C.Structure):
         ("alpha", c_f32), ("beta", c_f32), ("a_scale", c_f32),
         ("ep_inv_tau", c_f32), ("ep_ce_scale", c_f32),
         ("force_tile", c_i32), ("force_splitk", c_i32),
+        ("dyn_scalars", c_ptr),
     ]
 
 
@@ -71,7 +72,7 @@ PROTOTYPES = {
     "cgn_gemm_f32": (c_i32, [c_ptr, C.POINTER(GemmDesc)]),
     "cgn_gemm_plan": (c_i32, [C.POINTER(GemmDesc), C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32),
                               C.POINTER(c_i32)]),
-    "cgn_softmax_nll_fwd_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_i32, c_f32, c_ptr, c_ptr, c_ptr]),
+    "cgn_softmax_nll_fwd_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_i32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "cgn_lstm_seq_fwd_f32": (c_i32, [c_ptr, C.POINTER(LstmFwdSeq), c_i32, c_i32, c_i32, c_i32]),
     "cgn_lstm_seq_bwd_f32": (c_i32, [c_ptr, C.POINTER(LstmBwdSeq), c_i32, c_i32, c_i32, c_i32]),
     "cgn_act_maxpool_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr, c_i64, c_i32, c_ptr, c_i64]),
@@ -89,11 +90,12 @@ PROTOTYPES = {
     "cgn_highway_gate_fwd_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_i64]),
     "cgn_highway_gate_bwd_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
     "cgn_reparam_kld_fwd_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr]),
-    "cgn_reparam_kld_bwd_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_i32, c_i32, c_ptr]),
+    "cgn_reparam_kld_bwd_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_ptr, c_i32, c_i32, c_ptr]),
     "cgn_colsum_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_i32, c_f32, c_ptr, c_ptr, c_i64]),
     "cgn_sum_time_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr]),
     "cgn_rowdot_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_ptr]),
-    "cgn_adam_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32]),
+    "cgn_adam_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_ptr, c_f32]),
+    "cgn_incr_i32": (c_i32, [c_ptr, c_ptr]),
     "cgn_disc_head_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_f32, c_f32, c_ptr,
                                   c_ptr, c_ptr, c_ptr]),
     "cgn_disc_head_bwd_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_f32, c_ptr, c_ptr,

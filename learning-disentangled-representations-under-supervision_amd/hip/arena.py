@@ -67,9 +67,22 @@ class AdamState:
         self.m = torch.zeros(arena.size, dtype=torch.float32, device=arena.p.device)
         self.v = torch.zeros(arena.size, dtype=torch.float32, device=arena.p.device)
         self.step = 0
+        # device-resident copy of the step count, used when the step is replayed from a captured hipGraph (the graph
+        # bumps it with cgn_incr_i32 and the Adam kernel forms the bias corrections from it)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=arena.p.device)
 
-    def apply(self, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
-        self.step += 1
+    def apply(self, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8, dynamic=False):
+        """One Adam update. dynamic=True reads (and first increments) the device step count instead of the host's;
+        the caller (hip/graph.py) keeps `self.step` in line with it."""
         a = self.arena
+        if dynamic:
+            ops.incr(self.step_dev)
+            if a.size:
+                ops.adam(a.p, a.g, self.m, self.v, lr, 0, betas[0], betas[1], eps, grad_scale, dyn_step=self.step_dev)
+            return
+        self.step += 1
         if a.size:
             ops.adam(a.p, a.g, self.m, self.v, lr, self.step, betas[0], betas[1], eps, grad_scale)
+
+    def sync_device_step(self):
+        self.step_dev.fill_(self.step)

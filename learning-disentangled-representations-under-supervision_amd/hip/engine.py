@@ -15,7 +15,7 @@ from ._lib import ACT_RELU, ACT_TANH, Axis
 
 
 def _new(shape, dev, dtype=torch.float32):
-    return torch.empty(shape, dtype=dtype, device=dev)
+    return ops.alloc(shape, dev, dtype)
 
 
 LIN = Axis(1, 0, 0)
@@ -115,8 +115,11 @@ def highway_fwd(x, layers):
     return x, saved
 
 
-def highway_bwd(saved, layers, dy, grads, need_dx, beta=0.0):
-    """grads: list of dict(nw, nb, lw, lb, gw, gb) gradient tensors (may be None to skip parameter grads)."""
+def highway_bwd(saved, layers, dy, grads, need_dx, beta=0.0, side=None):
+    """grads: list of dict(nw, nb, lw, lb, gw, gb) gradient tensors (may be None to skip parameter grads).
+    side: optional context-manager factory; the parameter-gradient GEMMs run inside it (a side stream)."""
+    import contextlib
+    side = side or contextlib.nullcontext
     dx = None
     for li in range(len(layers) - 1, -1, -1):
         x, pre = saved[li]
@@ -128,9 +131,10 @@ def highway_bwd(saved, layers, dy, grads, need_dx, beta=0.0):
         views = (dpre[:, 0:S], dpre[:, Sp:Sp + S], dpre[:, 2 * Sp:2 * Sp + S])
         if grads is not None:
             g = grads[li]
-            for v, wn, bn in zip(views, ("nw", "lw", "gw"), ("nb", "lb", "gb")):
-                ops.gemm(v.t(), x, g[wn], beta=beta)
-                ops.colsum(v, g[bn], beta=beta)
+            with side():
+                for v, wn, bn in zip(views, ("nw", "lw", "gw"), ("nb", "lb", "gb")):
+                    ops.gemm(v.t(), x, g[wn], beta=beta)
+                    ops.colsum(v, g[bn], beta=beta)
         if li > 0 or need_dx:
             dx = ops.new2d(N, S, x.device)
             ops.gemm(views[0], p["nw"], dx)

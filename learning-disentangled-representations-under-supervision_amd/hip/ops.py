@@ -33,13 +33,29 @@ def _chk_i64(t, name):
 
 
 def workspace(device):
-    """Per-device split-K workspace (allocated once; the C library never allocates)."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    """Split-K / column-sum workspace, one per (device, stream): kernels launched on different streams may overlap, so
+    they must not share slabs. Allocated once per key (the C library never allocates)."""
+    idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None:
-        ws = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=torch.device("cuda", key))
+        with torch.cuda.stream(torch.cuda.default_stream(idx)):  # owned by the default stream's pool, never freed
+            ws = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=torch.device("cuda", idx))
         _workspaces[key] = ws
     return ws
+
+
+# Step-scoped temporaries. While KEEP is a list every tensor handed out by alloc() is also appended to it, so nothing is
+# returned to torch's caching allocator before the step ends: kernels of the same step running on different streams
+# (and the nodes of a captured hipGraph) can then never see a buffer recycled under them.
+KEEP = None
+
+
+def alloc(shape, dev, dtype=torch.float32):
+    t = torch.empty(shape, dtype=dtype, device=dev)
+    if KEEP is not None:
+        KEEP.append(t)
+    return t
 
 
 def _span_ok(t, base_off, axes_extents):
@@ -61,7 +77,8 @@ def _span_ok(t, base_off, axes_extents):
 
 
 def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, bias1=None,
-         a_m=None, a_k=None, b_k=None, b_n=None, a_exp=None, softmax_bwd=None, force_tile=0, force_splitk=0):
+         a_m=None, a_k=None, b_k=None, b_n=None, a_exp=None, softmax_bwd=None, force_tile=0, force_splitk=0,
+         dyn=None):
     """out[M,N] = epilogue(alpha * A @ B + beta*out + bias0 + bias1).
 
     `a` is viewed as A[M,K] and `b` as B[K,N]; arbitrary 2-D strides (so `w.t()` is free). The optional cgn Axis
@@ -140,6 +157,7 @@ def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, 
     d.workspace = _ptr(ws)
     d.workspace_bytes = ws.numel() * 4
     d.force_tile, d.force_splitk = force_tile, force_splitk
+    d.dyn_scalars = _ptr(dyn)
     prof = GEMM_PROFILE
     if prof is not None:
         t_, s_, ak, bk = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
@@ -163,8 +181,9 @@ def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, 
 GEMM_PROFILE = None
 
 
-def softmax_nll_fwd(logits, target, inv_tau):
-    """Returns (lse[M], nll[M], loss[1]) for logits [M,V] (row stride free), model/cgn.py:1086-1092."""
+def softmax_nll_fwd(logits, target, inv_tau, dyn=None):
+    """Returns (lse[M], nll[M], loss[1]) for logits [M,V] (row stride free), model/cgn.py:1086-1092.
+    dyn: optional device float tensor whose element 0 overrides inv_tau at run time (graph replay)."""
     lib = _lib.load()
     _chk_f32(logits, "logits"), _chk_i64(target, "target")
     if logits.dim() != 2 or logits.stride(1) != 1:
@@ -172,12 +191,11 @@ def softmax_nll_fwd(logits, target, inv_tau):
     M, V = logits.shape
     if target.numel() != M:
         raise ValueError("target must have M elements")
-    lse = torch.empty(M, dtype=torch.float32, device=logits.device)
-    nll = torch.empty(M, dtype=torch.float32, device=logits.device)
-    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    lse, nll, loss = alloc((M,), logits.device), alloc((M,), logits.device), alloc((1,), logits.device)
     with torch.cuda.device(logits.device):
         _lib.check(lib.cgn_softmax_nll_fwd_f32(_stream(), _ptr(logits), logits.stride(0), _ptr(target), M, V,
-                                               inv_tau, _ptr(lse), _ptr(nll), _ptr(loss)), "cgn_softmax_nll_fwd_f32")
+                                               inv_tau, _ptr(dyn), _ptr(lse), _ptr(nll), _ptr(loss)),
+                   "cgn_softmax_nll_fwd_f32")
     return lse, nll, loss
 
 
@@ -244,7 +262,7 @@ def pad4(n):
 
 def new2d(rows, cols, dev):
     """[rows, cols] fp32 view whose row stride is a multiple of 4 floats (16-byte aligned rows for float4 GEMM loads)."""
-    return torch.empty((rows, pad4(cols)), dtype=torch.float32, device=dev)[:, :cols]
+    return alloc((rows, pad4(cols)), dev)[:, :cols]
 
 
 def highway_gate_fwd(pre, S, out):
@@ -285,7 +303,7 @@ def reparam_kld_fwd(mulv, eps, c, zc, stdv, kld):
           _ptr(stdv), _ptr(kld))
 
 
-def reparam_kld_bwd(mulv, eps, g, kld_weight, dmulv):
+def reparam_kld_bwd(mulv, eps, g, kld_weight, dmulv, dyn=None):
     B, Z2 = mulv.shape
     Z = Z2 // 2
     for t, n in ((mulv, "mulv"), (eps, "eps"), (dmulv, "dmulv")):
@@ -296,7 +314,8 @@ def reparam_kld_bwd(mulv, eps, g, kld_weight, dmulv):
     if g is not None:
         ldg = _rows2d(g, "g")
         _req(g.shape[0] == B and g.shape[1] >= Z, "g must be [B, >=Z]")
-    _call("cgn_reparam_kld_bwd_f32", dmulv.device, _ptr(mulv), _ptr(eps), _ptr(g), ldg, kld_weight, B, Z, _ptr(dmulv))
+    _call("cgn_reparam_kld_bwd_f32", dmulv.device, _ptr(mulv), _ptr(eps), _ptr(g), ldg, kld_weight, _ptr(dyn), B, Z,
+          _ptr(dmulv))
     return dmulv
 
 
@@ -326,13 +345,19 @@ def rowdot(a, b, out):
     return out
 
 
-def adam(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+def incr(counter):
+    """counter[0] += 1 on the current stream (device-resident Adam step count)."""
+    _req(counter.is_cuda and counter.dtype == torch.int32 and counter.numel() == 1, "counter must be one device int32")
+    _call("cgn_incr_i32", counter.device, _ptr(counter))
+
+
+def adam(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, dyn_step=None):
     n = p.numel()
     for t, nme in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _chk_f32(t, nme)
         _req(t.is_contiguous() and t.numel() == n, "adam arenas must be contiguous and equally sized")
     _call("cgn_adam_f32", p.device, _ptr(p), _ptr(g), _ptr(m), _ptr(v), n, lr, beta1, beta2, eps, int(step),
-          grad_scale)
+          _ptr(dyn_step), grad_scale)
 
 
 def disc_head(feat, W, bias, logits, *, mask=None, y=None, w_ce=0.0, w_ent=0.0, p1=None, dlogits=None, stats=None):
@@ -498,7 +523,7 @@ def lincomb(terms, out=None):
     _req(1 <= n <= 4, "1..4 terms")
     dev = terms[0][1].device
     if out is None:
-        out = torch.empty(1, dtype=torch.float32, device=dev)
+        out = alloc((1,), dev)
     ptrs = (C.c_void_p * n)(*[t.data_ptr() for _, t in terms])
     coefs = (C.c_float * n)(*[float(c) for c, _ in terms])
     for _, t in terms:

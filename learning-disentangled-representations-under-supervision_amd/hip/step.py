@@ -10,6 +10,8 @@ reference's step closures (model/cgn.py:269-341 and :1049-1154; SURVEY.md §8a-1
   * encoder gradients = d(kld_coef*KLD)/dθ + (dz_out/dθ)ᵀ g.
 Parameter gradients land in the flat arenas (hip/arena.py); one Adam kernel per optimizer group.
 """
+import contextlib
+
 import torch
 
 from . import engine, ops
@@ -20,7 +22,7 @@ LIN = Axis(1, 0, 0)
 
 
 def _new(shape, dev, dtype=torch.float32):
-    return torch.empty(shape, dtype=dtype, device=dev)
+    return ops.alloc(shape, dev, dtype)
 
 
 class CGNStep:
@@ -54,6 +56,18 @@ class CGNStep:
         self.allreduce = allreduce
         self.world_size = world_size
         cfg = self.cfg
+        # Stream overlap (off by default: in eager mode the host, not the GPU, is the bound and every fork/join costs two
+        # more host calls; hip/graph.py turns it on while capturing the step into a hipGraph). side(k) regions run on
+        # side stream k, ordered after everything issued so far on the current stream; join(k) orders the current
+        # stream after side stream k.
+        self.overlap = False
+        self._side_streams = None
+        self._dirty = set()
+        # Device-resident step scalars {1/tau, 79/(tau*B*T), kld_coef/B, kld_coef}: when `dynamic` the kernels read these
+        # instead of immediates baked into their arguments, and Adam reads a device step count, so that a captured
+        # graph can be replayed while the schedules (utils/functional.py:28-42) advance.
+        self.dynamic = False
+        self.dyn = torch.zeros(4, dtype=torch.float32, device=dev)
         self.n_hw = model.encoder.hw1.num_layers
         self.Ks = list(cfg.sentiment_kernel_size)
         self.Cos = [cfg.sentiment_kernel_num] * len(self.Ks)
@@ -62,6 +76,43 @@ class CGNStep:
         return all(self.arenas[k].owns(v) for k, v in self.named_groups.items())
 
     # -------------------------------------------------------------------------------------------------------------
+    @contextlib.contextmanager
+    def side(self, k):
+        if not self.overlap:
+            yield
+            return
+        if self._side_streams is None:
+            self._side_streams = [torch.cuda.Stream(self.dev) for _ in range(2)]
+        st = self._side_streams[k]
+        ev = torch.cuda.Event()
+        ev.record()
+        st.wait_event(ev)
+        self._dirty.add(k)
+        with torch.cuda.stream(st):
+            yield
+
+    def join(self, *ks):
+        for k in ks:
+            if k in self._dirty:
+                ev = torch.cuda.Event()
+                ev.record(self._side_streams[k])
+                torch.cuda.current_stream(self.dev).wait_event(ev)
+                self._dirty.discard(k)
+
+    def _dyn(self, lo=0):
+        return self.dyn[lo:] if self.dynamic else None
+
+    def set_step_scalars(self, kld_coeff, temperature, n_rows, batch, pinned=None):
+        """Host -> device copy of the step scalars (async on the current stream when `pinned` is a pinned [4] tensor)."""
+        inv_tau = 1.0 / float(temperature)
+        vals = (inv_tau, 79.0 * inv_tau / n_rows, float(kld_coeff) / batch, float(kld_coeff))
+        if pinned is None:
+            pinned = torch.tensor(vals, dtype=torch.float32)
+        else:
+            for i, v in enumerate(vals):
+                pinned[i] = v
+        self.dyn.copy_(pinned, non_blocking=True)
+
     def new_optimizer(self, group):
         """Fresh Adam state for 'disc' | 'enc' | 'gen' (cgn.py:267, :1046-1047 create torch Adam objects likewise)."""
         return self.arenas[group].new_adam()
@@ -70,7 +121,7 @@ class CGNStep:
         a = state.arena
         if self.allreduce is not None and self.world_size > 1:
             self.allreduce(a.g)
-        state.apply(self.cfg.learning_rate, grad_scale=1.0 / self.world_size)
+        state.apply(self.cfg.learning_rate, grad_scale=1.0 / self.world_size, dynamic=self.dynamic)
 
     def _hw_layers(self, table):
         pre = "encoder.hw1."
@@ -192,14 +243,36 @@ class CGNStep:
         dhw = ops.new2d(N, Din, self.dev)
         for i, (s, dg, sfx) in enumerate(((sf, dgf, ""), (sr, dgr, "_reverse"))):
             if param_grads:
-                dg2 = engine.lstm_param_grads(s, dg, (hw_out, Axis(hw_out.stride(0), 0, 0)), G["encoder.rnn.weight_ih_l0" + sfx],
-                                              G["encoder.rnn.weight_hh_l0" + sfx], G["encoder.rnn.bias_ih_l0" + sfx],
-                                              G["encoder.rnn.bias_hh_l0" + sfx])
-            else:
-                dg2 = dg.view(N, 4 * He)
+                with self.side(1):  # parameter gradients leave the critical path (dX chain) when streams overlap
+                    engine.lstm_param_grads(s, dg, (hw_out, Axis(hw_out.stride(0), 0, 0)),
+                                            G["encoder.rnn.weight_ih_l0" + sfx], G["encoder.rnn.weight_hh_l0" + sfx],
+                                            G["encoder.rnn.bias_ih_l0" + sfx], G["encoder.rnn.bias_hh_l0" + sfx])
+            dg2 = dg.view(N, 4 * He)
             ops.gemm(dg2, P["encoder.rnn.weight_ih_l0" + sfx], dhw, beta=(0.0 if i == 0 else 1.0))
         return engine.highway_bwd(es["hw_saved"], self._hw_layers(P), dhw, self._hw_layers(G) if param_grads else None,
-                                  need_dx=True)
+                                  need_dx=True, side=lambda: self.side(1))
+
+    def total_losses(self, ce, kld, c_loss, z_loss, kld_coeff, use_disc=True, calc_z_loss=False):
+        """total_encoder_loss, total_generator_loss of cgn.py:1151-1152 from their parts (device scalars)."""
+        cfg = self.cfg
+        enc_loss = ops.lincomb([(79.0, ce), (float(kld_coeff), kld)])  # cgn.py:1151
+        gen_loss = ops.lincomb([(1.0, enc_loss), (cfg.lambda_c if use_disc else 0.0, c_loss),
+                                (cfg.lambda_z if calc_z_loss else 0.0, z_loss)])  # cgn.py:1152
+        return enc_loss, gen_loss
+
+    def wake_sleep(self, opts, d, kld_coeff, temperature, calc_z_loss=False):
+        """One wake-sleep step (train_functions.py:49-108 without the sampler): discriminator step, c inference,
+        encoder/generator step. opts: dict(disc, enc, gen); d: dict of device tensors (x_labelled, y_labelled,
+        x_generated, c_generated, mask_labelled, mask_generated, enc_word, enc_char, dec_word, target, c_uniform, eps).
+        With `overlap` the discriminator step and c inference run beside the encoder forward (they only meet at c)."""
+        with self.side(0):
+            d_losses = self.disc_train(opts["disc"], d["x_labelled"], d["y_labelled"], d["x_generated"],
+                                       d["c_generated"], d.get("mask_labelled"), d.get("mask_generated"))
+            c, _ = self.infer_c(d["enc_word"], d["c_uniform"])
+        eg_losses = self.enc_gen_train((opts["enc"], opts["gen"]), d["enc_word"], d["enc_char"], d["dec_word"],
+                                       d["target"], c, d["eps"], kld_coeff, temperature, calc_z_loss=calc_z_loss)
+        self.join(0, 1)
+        return d_losses, c, eg_losses
 
     # -------------------------------------------------------------------------------------------------------------
     def enc_gen_train(self, opts, enc_word, enc_char, dec_word, target, c_target, eps, kld_coeff, temperature,
@@ -232,6 +305,7 @@ class CGNStep:
         es = self._encoder_fwd(enc_in, B, L)
         mulv = es["mulv"]
         zc, std, kld = _new((B, Z + C), dev), _new((B, Z), dev), _new((1,), dev)
+        self.join(0)  # wake_sleep(): the discriminator step and c inference ran beside the encoder forward
         cvec = c_target.reshape(B, C)
         ops.reparam_kld_fwd(mulv, eps, cvec, zc, std, kld)
         # ---- generator (model/generator.py:45-64) --------------------------------------------------------------
@@ -257,7 +331,7 @@ class CGNStep:
         ops.gemm(h1, P["generator.fc.weight"].t(), logits, M=NT, K=Hg, a_m=h1ax, a_k=LIN, bias0=P["generator.fc.bias"])
         # ---- temperature softmax + CE (cgn.py:1086-1092) -------------------------------------------------------
         tgt = target.reshape(-1)
-        lse, nll, ce = ops.softmax_nll_fwd(logits, tgt, inv_tau)
+        lse, nll, ce = ops.softmax_nll_fwd(logits, tgt, inv_tau, dyn=self._dyn())
         dummy = lse  # any valid device pointer for unused GEMM operands (K = 0)
         need_soft = use_disc or calc_z_loss
         c_loss, z_loss = _new((1,), dev), _new((1,), dev)
@@ -266,7 +340,7 @@ class CGNStep:
         if need_soft:
             # ---- soft embedding (cgn.py:1103-1108): softmax(logits/tau) @ E, probabilities formed in the A loader
             out_emb = _new((NT, E), dev)
-            ops.gemm(logits, table, out_emb, a_exp=(inv_tau, lse))
+            ops.gemm(logits, table, out_emb, a_exp=(inv_tau, lse), dyn=self._dyn())
             d_out_emb = _new((NT, E), dev)
             ops.fill(d_out_emb, 0.0)  # rows t = T-1 stay zero: out_embedding[:, :-1, :] (cgn.py:1108)
         if use_disc:
@@ -296,9 +370,10 @@ class CGNStep:
                 d_enc_in2 = self._encoder_bwd(es2, dmulv2, param_grads=False)
                 # add the word-part gradient into d_out_emb rows (b, t < L)
                 ops.add3d(d_enc_in2.unflatten(0, (B, L))[:, :, :E], d_out_emb.view(B, T, E)[:, :L])
-        enc_loss = ops.lincomb([(79.0, ce), (float(kld_coeff), kld)])  # cgn.py:1151
-        gen_loss = ops.lincomb([(1.0, enc_loss), (cfg.lambda_c if use_disc else 0.0, c_loss),
-                                (cfg.lambda_z if calc_z_loss else 0.0, z_loss)])  # cgn.py:1152
+        if self.dynamic:
+            enc_loss = gen_loss = None  # kld_coef is a device scalar here: hip/graph.py forms the totals after replay
+        else:
+            enc_loss, gen_loss = self.total_losses(ce, kld, c_loss, z_loss, kld_coeff, use_disc, calc_z_loss)
         if not train:
             return ce, kld, z_loss, c_loss, enc_loss, gen_loss
         # ---- backward through softmax/CE + soft embedding, fused, in place over the logits ----------------------
@@ -307,50 +382,58 @@ class CGNStep:
             ops.rowdot(d_out_emb, out_emb, rowdot)
             ops.gemm(d_out_emb, table.t(), logits,
                      softmax_bwd=dict(logits=logits, lse=lse, rowdot=rowdot, target=tgt, inv_tau=inv_tau,
-                                      ce_scale=79.0 * inv_tau / NT))
+                                      ce_scale=79.0 * inv_tau / NT), dyn=self._dyn())
         else:
             # CE only (initial VAE training, cgn.py:639-644): same epilogue with an empty product (K = 0)
             ops.fill(rowdot, 0.0)
             ops.gemm(dummy.view(NT, 1)[:, :0], table.t()[:0], logits,
                      softmax_bwd=dict(logits=logits, lse=lse, rowdot=rowdot, target=tgt, inv_tau=inv_tau,
-                                      ce_scale=79.0 * inv_tau / NT))
+                                      ce_scale=79.0 * inv_tau / NT), dyn=self._dyn())
         dlogits = logits
-        ops.gemm(dlogits.t(), h1, G["generator.fc.weight"], N=Hg, K=NT, b_k=h1ax, b_n=LIN)
-        ops.colsum(dlogits, G["generator.fc.bias"])
         dH1 = _new((NT, Hg), dev)
         ops.gemm(dlogits, P["generator.fc.weight"], dH1)
+        # forked AFTER dH1 (the side stream waits for everything issued so far): dH1 heads the critical path and must
+        # not share the GPU with the equally large dW_fc product; dW_fc then runs beside the latency-bound LSTM steps
+        with self.side(1):
+            ops.gemm(dlogits.t(), h1, G["generator.fc.weight"], N=Hg, K=NT, b_k=h1ax, b_n=LIN)
+            ops.colsum(dlogits, G["generator.fc.bias"])
         # ---- generator LSTM backward ---------------------------------------------------------------------------
         dc1 = _new((B, Hg), dev)
         ops.fill(dc1, 0.0)
         (dg1,) = engine.lstm_run_bwd([g1], [P["generator.rnn.weight_hh_l1"]], [(dH1, T * Hg, Hg)], [None], [dc1])
-        dg1_2 = engine.lstm_param_grads(g1, dg1, (h0, h0ax), G["generator.rnn.weight_ih_l1"],
-                                        G["generator.rnn.weight_hh_l1"], G["generator.rnn.bias_ih_l1"],
-                                        G["generator.rnn.bias_hh_l1"])
+        with self.side(1):
+            engine.lstm_param_grads(g1, dg1, (h0, h0ax), G["generator.rnn.weight_ih_l1"],
+                                    G["generator.rnn.weight_hh_l1"], G["generator.rnn.bias_ih_l1"],
+                                    G["generator.rnn.bias_hh_l1"])
         dH0 = _new((NT, Hg), dev)
-        ops.gemm(dg1_2, P["generator.rnn.weight_ih_l1"], dH0)
+        ops.gemm(dg1.view(NT, 4 * Hg), P["generator.rnn.weight_ih_l1"], dH0)
         dc0 = _new((B, Hg), dev)
         ops.fill(dc0, 0.0)
         (dg0,) = engine.lstm_run_bwd([g0], [P["generator.rnn.weight_hh_l0"]], [(dH0, T * Hg, Hg)], [None], [dc0])
         dWih0 = G["generator.rnn.weight_ih_l0"]
-        engine.lstm_param_grads(g0, dg0, (gen_emb, Axis(E, 0, 0)), dWih0[:, :E], G["generator.rnn.weight_hh_l0"],
-                                G["generator.rnn.bias_ih_l0"], G["generator.rnn.bias_hh_l0"])
         dsum = _new((B, 4 * Hg), dev)
         ops.sum_time(dg0, dsum)
-        ops.gemm(dsum.t(), zc, dWih0[:, E:])
+        with self.side(1):
+            engine.lstm_param_grads(g0, dg0, (gen_emb, Axis(E, 0, 0)), dWih0[:, :E], G["generator.rnn.weight_hh_l0"],
+                                    G["generator.rnn.bias_ih_l0"], G["generator.rnn.bias_hh_l0"])
+            ops.gemm(dsum.t(), zc, dWih0[:, E:])
         dzc = _new((B, Z + C), dev)
         ops.gemm(dsum, Wih0[:, E:], dzc)  # g = dzc[:, :Z] = d(79*CE + recon)/dz  (cgn.py:1099, 1142)
         if capture is not None:
+            self.join(1)
             capture["g"] = dzc[:, :Z].clone()
             capture["gen_grads"] = {n: g.clone() for n, g in self.arenas["gen"].grads.items()}
         if not joint:
-            self._optim_step(opts[1])  # cgn.py:1143
+            with self.side(1):  # the generator's Adam step follows its gradients; the encoder backward does not wait
+                self._optim_step(opts[1])  # cgn.py:1143
         # ---- encoder backward (cgn.py:1145-1149): kld_coef*KLD + z_out.backward(g) ---------------------------------
         dmulv = _new((B, 2 * Z), dev)
-        ops.reparam_kld_bwd(mulv, eps, dzc, float(kld_coeff) / B, dmulv)
+        ops.reparam_kld_bwd(mulv, eps, dzc, float(kld_coeff) / B, dmulv, dyn=self._dyn(2))
         d_enc_in = self._encoder_bwd(es, dmulv, param_grads=True)
         dtf = _new((N, S), dev)
         ops.copy2d(d_enc_in[:, E:], dtf)
         engine.tdnn_bwd(tsaved, tk, dtf, self._tdnn_kernels(G), G["embedding.char_embed.weight"])
+        self.join(1)
         if capture is not None:
             capture["enc_grads"] = {n: g.clone() for n, g in self.arenas["enc"].grads.items()}
         self._optim_step(opts[0])  # cgn.py:1149

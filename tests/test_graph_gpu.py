@@ -1,0 +1,80 @@
+"""GPU: the wake-sleep step replayed from a captured hipGraph (hip/graph.py: device-resident schedules and Adam step
+counts, side-stream overlap) must train exactly like the eager step issued kernel by kernel."""
+import pytest
+import torch
+
+from oracle import cgn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(max_word_len=12, max_seq_len=10, word_vocab_size=1200, char_vocab_size=64, encoder_rnn_size=64,
+           latent_variable_size=32, decoder_rnn_size=96, sentiment_kernel_num=20)
+SCHED = [(0.31, 0.97), (0.52, 0.91), (0.88, 0.64), (0.93, 0.60)]  # (kld_coef, temperature) per step
+
+
+def _build(dev):
+    import ldrs_amd  # noqa: F401
+    from ldrs_amd.model.cgn import Controlled_Generation_Sentence
+    from ldrs_amd.utils.config import Config
+    kw = dict(CFG)
+    pos = [kw.pop(k) for k in ("max_word_len", "max_seq_len", "word_vocab_size", "char_vocab_size")]
+    cfg = Config(*pos, 1e-3, 7.9, 0.1, 0.1, 1.0, **kw)
+    ocfg = O.OracleConfig(**CFG)
+    torch.manual_seed(3)
+    model = Controlled_Generation_Sentence(cfg, O.synthetic_word_embed(ocfg)).to(dev)
+    eng = model.step_engine()
+    opts = dict(disc=eng.new_optimizer("disc"), enc=eng.new_optimizer("enc"), gen=eng.new_optimizer("gen"))
+    return model, eng, opts, ocfg
+
+
+def _batches(ocfg, dev, n, B=8, L=10):
+    out = []
+    for i in range(n):
+        d = O.synthetic_batch(ocfg, B, L, seed=100 + i)
+        out.append({k: v.to(dev).contiguous() for k, v in d.items()})
+    return out
+
+
+@pytest.mark.parametrize("calc_z,overlap", [(False, True), (True, True), (False, False)])
+def test_graph_replay_trains_like_eager(dev, calc_z, overlap):
+    from ldrs_amd.hip.graph import GraphedWakeSleep
+    m_e, eng_e, opts_e, ocfg = _build(dev)
+    m_g, eng_g, opts_g, _ = _build(dev)
+    for (n, p), (_, q) in zip(m_e.named_parameters(), m_g.named_parameters()):
+        assert torch.equal(p, q), n
+    data = _batches(ocfg, dev, len(SCHED))
+
+    eager_losses = []
+    for (kc, tau), d in zip(SCHED, data):
+        dl, c, eg = eng_e.wake_sleep(opts_e, d, kc, tau, calc_z_loss=calc_z)
+        eager_losses.append([float(x) for x in dl] + [float(x) for x in eg] + [float(c.sum())])
+
+    # step 1 = the warm-up step inside the constructor (a real training step on data[0] with SCHED[0])
+    g = GraphedWakeSleep(eng_g, opts_g, data[0], calc_z_loss=calc_z, overlap=overlap, warmup_kld=SCHED[0][0],
+                         warmup_tau=SCHED[0][1])
+    graph_losses = []
+    for (kc, tau), d in zip(SCHED[1:], data[1:]):
+        dl, c, eg = g(kc, tau, d)
+        graph_losses.append([float(x) for x in dl] + [float(x) for x in eg] + [float(c.sum())])
+    torch.cuda.synchronize()
+
+    for le, lg in zip(eager_losses[1:], graph_losses):
+        for a, b in zip(le, lg):
+            assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (le, lg)
+    assert all(st.step == len(SCHED) for st in opts_g.values())
+    assert all(int(st.step_dev.item()) == len(SCHED) for st in opts_g.values())
+    worst = 0.0
+    for (n, p), (_, q) in zip(m_e.named_parameters(), m_g.named_parameters()):
+        err = (p - q).abs().max().item() / max(p.abs().max().item(), 1e-12)
+        worst = max(worst, err)
+        assert err <= 2e-6, (n, err)  # device-side vs host-side double pow() in Adam's bias correction
+
+
+def test_graph_rejects_other_shapes(dev):
+    from ldrs_amd.hip.graph import GraphedWakeSleep
+    _, eng, opts, ocfg = _build(dev)
+    data = _batches(ocfg, dev, 1)
+    g = GraphedWakeSleep(eng, opts, data[0])
+    small = {k: v[:4] for k, v in data[0].items()}
+    with pytest.raises(ValueError):
+        g.load(small)
