@@ -113,6 +113,24 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_step_fwd_kernel(const FwdParams 
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = {0.f, 0.f, 0.f, 0.f};
 
+    // Operands of the cell update (independent of the product): requested NOW, on clamped addresses and by every wave
+    // (no branch), so their round trip overlaps the W_hh / h loads instead of following the LDS reduction.
+    const int er = wave & 3;
+    const int eb = b0 + (lane >> 4) * 4 + er, ej = j0 + (lane & 15);
+    const int ebc = min(eb, B - 1), ejc = min(ej, H - 1);
+    float pre_x[4], pre_e[4];
+    {
+        const float* xg = sq.xg + ((long)ebc * T + t) * 4 * H + ejc;
+        const float* xe = sq.xg_extra ? sq.xg_extra + (long)ebc * 4 * H + ejc : xg;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            pre_x[g] = xg[g * H];
+            pre_e[g] = xe[g * H];
+        }
+    }
+    const float cprev_pf = sq.cbuf[((long)ebc * (T + 1) + slot_prev) * H + ejc];
+    const bool has_extra = sq.xg_extra != nullptr;
+
     constexpr int CH = 4;
     for (int c0 = c_beg; c0 < c_end; c0 += CH) {
         f32x4 a[CH], w[4][CH];
@@ -151,21 +169,20 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_step_fwd_kernel(const FwdParams 
     const int j = j0 + (lane & 15);
     if (b < B && j < H) {
         float pre[4];
-        const float* xg = sq.xg + ((long)b * T + t) * 4 * H;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float v = 0.f;
 #pragma unroll
             for (int wv = 0; wv < LSTM_NW; ++wv) v += red[wv][g * 4 + r][lane];
-            v += xg[g * H + j];
-            if (sq.xg_extra) v += sq.xg_extra[(long)b * 4 * H + g * H + j];
+            v += pre_x[g];
+            if (has_extra) v += pre_e[g];
             pre[g] = v;
         }
         const float ig = cgn_sigmoid(pre[0]);
         const float fg = cgn_sigmoid(pre[1]);
         const float gg = tanhf(pre[2]);
         const float og = cgn_sigmoid(pre[3]);
-        const float cprev = sq.cbuf[((long)b * (T + 1) + slot_prev) * H + j];
+        const float cprev = cprev_pf;
         const float cn = fg * cprev + ig * gg;
         const float hn = og * tanhf(cn);
         float* go = sq.gates + ((long)b * T + t) * 4 * H;
@@ -193,6 +210,17 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_step_bwd_kernel(const BwdParams 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, q = lane >> 4;
     const int K = 4 * H;
+
+    // operands of the gate-gradient update, requested before the product (see the forward kernel)
+    const int er = wave & 3;
+    const int eb = b0 + (lane >> 4) * 4 + er, ej = j0 + (lane & 15);
+    const int ebc = min(eb, B - 1), ejc = min(ej, H - 1);
+    const float* gt_pf = sq.gates + ((long)ebc * T + t) * K + ejc;
+    const float ig_pf = gt_pf[0], fg_pf = gt_pf[H], gg_pf = gt_pf[2 * H], og_pf = gt_pf[3 * H];
+    const float cprev_pf = sq.cbuf[((long)ebc * (T + 1) + slot_prev) * H + ejc];
+    const float cout_pf = sq.cbuf[((long)ebc * (T + 1) + slot_out) * H + ejc];
+    const float dcs_pf = sq.dc_state[(long)ebc * H + ejc];
+    const float dhx_pf = sq.dh_ext ? sq.dh_ext[(long)ebc * sq.dh_bs + (long)t * sq.dh_ts + ejc] : 0.f;
 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if (!first) {
@@ -238,12 +266,11 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_step_bwd_kernel(const BwdParams 
 #pragma unroll
         for (int wv = 0; wv < LSTM_NW; ++wv) dh += red[wv][r][lane];
         if (first && sq.dh_seed) dh += sq.dh_seed[(long)b * H + j];
-        if (sq.dh_ext) dh += sq.dh_ext[(long)b * sq.dh_bs + (long)t * sq.dh_ts + j];
-        const float* gt = sq.gates + ((long)b * T + t) * K;
-        const float ig = gt[j], fg = gt[H + j], gg = gt[2 * H + j], og = gt[3 * H + j];
-        const float cprev = sq.cbuf[((long)b * (T + 1) + slot_prev) * H + j];
-        const float tc = tanhf(sq.cbuf[((long)b * (T + 1) + slot_out) * H + j]);
-        const float dc = sq.dc_state[(long)b * H + j] + dh * og * (1.f - tc * tc);
+        dh += dhx_pf;
+        const float ig = ig_pf, fg = fg_pf, gg = gg_pf, og = og_pf;
+        const float cprev = cprev_pf;
+        const float tc = tanhf(cout_pf);
+        const float dc = dcs_pf + dh * og * (1.f - tc * tc);
         float* dg = sq.dgates + ((long)b * T + t) * K;
         dg[j] = dc * gg * ig * (1.f - ig);
         dg[H + j] = dc * cprev * fg * (1.f - fg);
