@@ -155,9 +155,17 @@ __global__ __launch_bounds__(PW_NT) void colsum_partial_kernel(const float* __re
     const int c = blockIdx.x * PW_NT + threadIdx.x;
     if (c >= Cn) return;
     const int r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += x[(long)r * ld + c];
-    part[(long)blockIdx.y * Cn + c] = s;
+    // four independent chains keep 4+ loads in flight per thread; the summation order is fixed (reproducible)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {
+        s0 += x[(long)r * ld + c];
+        s1 += x[(long)(r + 1) * ld + c];
+        s2 += x[(long)(r + 2) * ld + c];
+        s3 += x[(long)(r + 3) * ld + c];
+    }
+    for (; r < r1; ++r) s0 += x[(long)r * ld + c];
+    part[(long)blockIdx.y * Cn + c] = (s0 + s1) + (s2 + s3);
 }
 __global__ __launch_bounds__(PW_NT) void colsum_final_kernel(const float* __restrict__ part, int nchunk, int Cn,
                                                              float beta, float* __restrict__ out) {
@@ -473,7 +481,7 @@ extern "C" int cgn_colsum_f32(void* stream, const float* x, int64_t ld, int32_t 
                               float* workspace, int64_t workspace_bytes) {
     CGN_CHECK_ARG(R >= 0 && Cn > 0);
     CGN_CHECK_ARG(x && out && ld >= Cn && workspace);
-    int nchunk = cgn_cdiv(R, 64);
+    int nchunk = cgn_cdiv(R, 16);  // short row chunks: enough blocks to fill 256 CUs even for narrow matrices
     if (nchunk > 64) nchunk = 64;
     if (nchunk < 1) nchunk = 1;
     if ((long)nchunk * Cn * 4 > workspace_bytes) return CGN_ERR_WORKSPACE;
