@@ -94,11 +94,19 @@ __global__ __launch_bounds__(PW_NT) void highway_fwd_kernel(const float* __restr
 __global__ __launch_bounds__(PW_NT) void highway_bwd_kernel(const float* __restrict__ pre, int N, int S, int Sp,
                                                             const float* __restrict__ dy, long ldy,
                                                             float* __restrict__ dpre) {
-    const long total = (long)N * S;
+    // runs over the padded width: the pad columns [S, Sp) of each block are written as zeros, so dpre can feed GEMMs
+    // whose K or M axis spans the whole padded [N, 3*Sp] buffer (fused N|L|G products)
+    const long total = (long)N * Sp;
     for (long i = (long)blockIdx.x * PW_NT + threadIdx.x; i < total; i += (long)gridDim.x * PW_NT) {
-        const int r = (int)(i / S), c = (int)(i % S);
-        const float* p = pre + (long)r * 3 * Sp;
+        const int r = (int)(i / Sp), c = (int)(i % Sp);
         float* d = dpre + (long)r * 3 * Sp;
+        if (c >= S) {
+            d[c] = 0.f;
+            d[Sp + c] = 0.f;
+            d[2 * Sp + c] = 0.f;
+            continue;
+        }
+        const float* p = pre + (long)r * 3 * Sp;
         const float n = p[c], li = p[Sp + c], g = cgn_sigmoid(p[2 * Sp + c]);
         const float g_y = dy[(long)r * ldy + c];
         d[c] = (n > 0.f) ? g_y * g : 0.f;
@@ -451,7 +459,7 @@ extern "C" int cgn_highway_gate_bwd_f32(void* stream, const float* pre, int32_t 
     CGN_CHECK_ARG(N >= 0 && S > 0 && Sp >= S);
     if (N == 0) return CGN_OK;
     CGN_CHECK_ARG(pre && dy && dpre && ldy >= S);
-    hipLaunchKernelGGL(highway_bwd_kernel, dim3(pw_blocks((long)N * S)), dim3(PW_NT), 0, S_(stream), pre, N, S, Sp, dy,
+    hipLaunchKernelGGL(highway_bwd_kernel, dim3(pw_blocks((long)N * Sp)), dim3(PW_NT), 0, S_(stream), pre, N, S, Sp, dy,
                        (long)ldy, dpre);
     CGN_LAUNCH_CHECK();
     return CGN_OK;

@@ -12,21 +12,65 @@ from . import ops
 ALIGN = 64  # floats (256 B): keeps every tensor 16-byte aligned for float4 access
 
 
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
 class ParamArena:
-    def __init__(self, named_params, device):
-        """named_params: list of (name, nn.Parameter). Parameters are re-pointed at views of the arena."""
+    def __init__(self, named_params, device, fused=None):
+        """named_params: list of (name, nn.Parameter). Parameters are re-pointed at views of the arena.
+
+        fused: optional {group_name: [param names]} of equally shaped 2-D weights (or 1-D biases) that are laid out
+        back to back, each member padded to a multiple of 4 rows (elements), so that the whole group is ALSO one
+        [sum(padded rows), cols] matrix (one vector): `self.fused[group_name] = (param_view, grad_view, padded_rows)`.
+        One GEMM against that matrix then replaces one GEMM per member (the highway's N|L|G products, mu|logvar).
+        The pad rows start at zero and stay zero: their gradients are written as zeros by the fused kernels, and Adam
+        maps a zero gradient with zero moments to a zero update."""
         self.names = [n for n, _ in named_params]
+        table = dict(named_params)
+        member_of = {}
+        for gname, members in (fused or {}).items():
+            shapes = {tuple(table[m].shape) for m in members}
+            if len(shapes) != 1 or len(next(iter(shapes))) not in (1, 2):
+                raise ValueError("fused group %s needs equally shaped 1-D or 2-D members" % gname)
+            for m in members:
+                member_of[m] = gname
         self.offsets, off = {}, 0
-        for n, p in named_params:
+        self._group_span = {}
+        placed = set()
+
+        def place(n, p, align):
+            nonlocal off
             shape = tuple(p.shape)
             # big matrices whose rows are not a multiple of 4 floats (e.g. [*, 825] highway / LSTM input weights,
             # [*, 365] generator input weights) get a padded row stride so that GEMM operand rows are 16-byte aligned
             ld = shape[-1]
             if p.dim() == 2 and shape[0] >= 64 and shape[1] >= 64 and shape[1] % 4:
-                ld = (shape[1] + 3) // 4 * 4
+                ld = _pad4(shape[1])
             ne = p.numel() // shape[-1] * ld if p.dim() >= 1 and shape[-1] else p.numel()
             self.offsets[n] = (off, ne, shape, ld)
-            off += (ne + ALIGN - 1) // ALIGN * ALIGN
+            if align:
+                off += (ne + ALIGN - 1) // ALIGN * ALIGN
+            else:  # fused member: pad to 4 rows (2-D) / 4 elements (1-D), no gap to the next member
+                rows = _pad4(shape[0])
+                off += rows * ld if p.dim() == 2 else rows
+            return ld
+
+        for n, p in named_params:
+            if n in placed:
+                continue
+            g = member_of.get(n)
+            if g is None:
+                place(n, p, True)
+                placed.add(n)
+                continue
+            start = off
+            for m in fused[g]:
+                ld = place(m, table[m], False)
+                placed.add(m)
+            shape = tuple(table[fused[g][0]].shape)
+            self._group_span[g] = (start, off - start, _pad4(shape[0]), ld if len(shape) == 2 else None, shape)
+            off = (off + ALIGN - 1) // ALIGN * ALIGN
         self.size = off
         self.p = torch.zeros(off, dtype=torch.float32, device=device)
         self.g = torch.zeros(off, dtype=torch.float32, device=device)
@@ -46,6 +90,16 @@ class ParamArena:
             p.grad = gview
             self.params[n] = p
             self.grads[n] = gview
+        self.fused = {}
+        for g, (start, ne, prow, ld, shape) in self._group_span.items():
+            k = len(fused[g])
+
+            def gview(flat):
+                if ld is None:
+                    return flat[start:start + ne]
+                return flat[start:start + ne].view(k * prow, ld)[:, :shape[1]]
+
+            self.fused[g] = (gview(self.p), gview(self.g), prow)
 
     def owns(self, named_params):
         """True while every parameter still aliases this arena (a .cuda()/.to() on the module breaks that)."""

@@ -98,16 +98,21 @@ def tdnn_bwd(saved, kernels, dfeat, dkernels, dchar_table, beta=0.0):
 # highway (selfModules/highway.py:27-46), f = relu as used by the encoder (model/encoder.py:15)
 # ------------------------------------------------------------------------------------------------------------------
 def highway_fwd(x, layers):
-    """x [N,S]; layers: list of dict(nw, nb, lw, lb, gw, gb). Returns y and the per-layer saved (input, pre).
-    Activations live in buffers whose rows/blocks start on 16-byte boundaries (S = 825 is odd in the reference)."""
+    """x [N,S]; layers: list of dict(nw, nb, lw, lb, gw, gb[, wcat, bcat]). Returns y and the per-layer saved
+    (input, pre). Activations live in buffers whose rows/blocks start on 16-byte boundaries (S = 825 is odd in the
+    reference). With wcat [3*Sp, S] / bcat [3*Sp] (the three weights stacked in the arena, hip/arena.py `fused`) the
+    N|L|G pre-activations are ONE GEMM."""
     N, S = x.shape
     Sp = ops.pad4(S)
     saved = []
     for p in layers:
         pre = _new((N, 3 * Sp), x.device)
-        ops.gemm(x, p["nw"].t(), pre[:, 0:S], bias0=p["nb"])
-        ops.gemm(x, p["lw"].t(), pre[:, Sp:Sp + S], bias0=p["lb"])
-        ops.gemm(x, p["gw"].t(), pre[:, 2 * Sp:2 * Sp + S], bias0=p["gb"])
+        if p.get("wcat") is not None:
+            ops.gemm(x, p["wcat"].t(), pre, bias0=p["bcat"])
+        else:
+            ops.gemm(x, p["nw"].t(), pre[:, 0:S], bias0=p["nb"])
+            ops.gemm(x, p["lw"].t(), pre[:, Sp:Sp + S], bias0=p["lb"])
+            ops.gemm(x, p["gw"].t(), pre[:, 2 * Sp:2 * Sp + S], bias0=p["gb"])
         y = ops.new2d(N, S, x.device)
         ops.highway_gate_fwd(pre, S, y)
         saved.append((x, pre))
@@ -116,8 +121,10 @@ def highway_fwd(x, layers):
 
 
 def highway_bwd(saved, layers, dy, grads, need_dx, beta=0.0, side=None):
-    """grads: list of dict(nw, nb, lw, lb, gw, gb) gradient tensors (may be None to skip parameter grads).
-    side: optional context-manager factory; the parameter-gradient GEMMs run inside it (a side stream)."""
+    """grads: list of dict(nw, nb, lw, lb, gw, gb[, wcat, bcat]) gradient tensors (may be None to skip parameter
+    grads). side: optional context-manager factory; the parameter-gradient GEMMs run inside it (a side stream).
+    The gate backward writes zeros into the pad columns of dpre, so the stacked forms (one dW GEMM, one column sum,
+    one dX GEMM over K = 3*Sp) see exact zeros for the pad rows of wcat."""
     import contextlib
     side = side or contextlib.nullcontext
     dx = None
@@ -132,14 +139,21 @@ def highway_bwd(saved, layers, dy, grads, need_dx, beta=0.0, side=None):
         if grads is not None:
             g = grads[li]
             with side():
-                for v, wn, bn in zip(views, ("nw", "lw", "gw"), ("nb", "lb", "gb")):
-                    ops.gemm(v.t(), x, g[wn], beta=beta)
-                    ops.colsum(v, g[bn], beta=beta)
+                if g.get("wcat") is not None:
+                    ops.gemm(dpre.t(), x, g["wcat"], beta=beta)
+                    ops.colsum(dpre, g["bcat"], beta=beta)
+                else:
+                    for v, wn, bn in zip(views, ("nw", "lw", "gw"), ("nb", "lb", "gb")):
+                        ops.gemm(v.t(), x, g[wn], beta=beta)
+                        ops.colsum(v, g[bn], beta=beta)
         if li > 0 or need_dx:
             dx = ops.new2d(N, S, x.device)
-            ops.gemm(views[0], p["nw"], dx)
-            ops.gemm(views[1], p["lw"], dx, beta=1.0)
-            ops.gemm(views[2], p["gw"], dx, beta=1.0)
+            if p.get("wcat") is not None:
+                ops.gemm(dpre, p["wcat"], dx)
+            else:
+                ops.gemm(views[0], p["nw"], dx)
+                ops.gemm(views[1], p["lw"], dx, beta=1.0)
+                ops.gemm(views[2], p["gw"], dx, beta=1.0)
             dy = dx
     return dx
 

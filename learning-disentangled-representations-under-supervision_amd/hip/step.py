@@ -48,7 +48,17 @@ class CGNStep:
             else:
                 groups["enc"].append((n, p))  # cgn.py:676-683: encoder + embedding + e2mu + e2logvar
         self.named_groups = groups
-        self.arenas = {k: ParamArena(v, dev) for k, v in groups.items()}
+        # weights that always multiply the same activations are stacked in the arena (one GEMM instead of one each)
+        self.n_hw = model.encoder.hw1.num_layers
+        fused_enc = {}
+        for l in range(self.n_hw):
+            pre = "encoder.hw1."
+            fused_enc["hw%d.w" % l] = [pre + "%s_module_%d-0" % (k, l) for k in ("nonlinear", "linear", "gate")]
+            fused_enc["hw%d.b" % l] = [pre + "%s_module_%d-1" % (k, l) for k in ("nonlinear", "linear", "gate")]
+        if model.config.latent_variable_size % 4 == 0:
+            fused_enc["e2.w"] = ["e2mu.weight", "e2logvar.weight"]
+            fused_enc["e2.b"] = ["e2mu.bias", "e2logvar.bias"]
+        self.arenas = {k: ParamArena(v, dev, fused=fused_enc if k == "enc" else None) for k, v in groups.items()}
         self.P = {n: p.data for n, p in named.items()}
         self.G = {}
         for a in self.arenas.values():
@@ -68,7 +78,6 @@ class CGNStep:
         # graph can be replayed while the schedules (utils/functional.py:28-42) advance.
         self.dynamic = False
         self.dyn = torch.zeros(4, dtype=torch.float32, device=dev)
-        self.n_hw = model.encoder.hw1.num_layers
         self.Ks = list(cfg.sentiment_kernel_size)
         self.Cos = [cfg.sentiment_kernel_num] * len(self.Ks)
 
@@ -123,11 +132,19 @@ class CGNStep:
             self.allreduce(a.g)
         state.apply(self.cfg.learning_rate, grad_scale=1.0 / self.world_size, dynamic=self.dynamic)
 
+    def _fused(self, name, table):
+        """The stacked parameter (table is self.P) or gradient (self.G) view of an arena group, or None."""
+        f = self.arenas["enc"].fused.get(name)
+        if f is None:
+            return None
+        return f[0] if table is self.P else f[1]
+
     def _hw_layers(self, table):
         pre = "encoder.hw1."
         return [dict(nw=table[pre + "nonlinear_module_%d-0" % l], nb=table[pre + "nonlinear_module_%d-1" % l],
                      lw=table[pre + "linear_module_%d-0" % l], lb=table[pre + "linear_module_%d-1" % l],
-                     gw=table[pre + "gate_module_%d-0" % l], gb=table[pre + "gate_module_%d-1" % l])
+                     gw=table[pre + "gate_module_%d-0" % l], gb=table[pre + "gate_module_%d-1" % l],
+                     wcat=self._fused("hw%d.w" % l, table), bcat=self._fused("hw%d.b" % l, table))
                 for l in range(self.n_hw)]
 
     def _conv_params(self, table):
@@ -211,8 +228,12 @@ class CGNStep:
         ops.copy2d(sf.c_final(), ctx[:, :He])
         ops.copy2d(sr.c_final(), ctx[:, He:])
         mulv = _new((B, 2 * Z), self.dev)
-        ops.gemm(ctx, P["e2mu.weight"].t(), mulv[:, :Z], bias0=P["e2mu.bias"])
-        ops.gemm(ctx, P["e2logvar.weight"].t(), mulv[:, Z:], bias0=P["e2logvar.bias"])
+        w2 = self._fused("e2.w", P)
+        if w2 is not None:  # [mu | logvar] in one product (cgn.py:91-92)
+            ops.gemm(ctx, w2.t(), mulv, bias0=self._fused("e2.b", P))
+        else:
+            ops.gemm(ctx, P["e2mu.weight"].t(), mulv[:, :Z], bias0=P["e2mu.bias"])
+            ops.gemm(ctx, P["e2logvar.weight"].t(), mulv[:, Z:], bias0=P["e2logvar.bias"])
         return dict(hw_out=hw_out, hw_saved=hw_saved, sf=sf, sr=sr, ctx=ctx, mulv=mulv, B=B, L=L)
 
     def _encoder_bwd(self, es, dmulv, param_grads):
@@ -225,7 +246,13 @@ class CGNStep:
         ctx = es["ctx"]
         dctx = _new((B, 2 * He), self.dev)
         dmu, dlv = dmulv[:, :Z], dmulv[:, Z:]
-        if param_grads:
+        w2 = self._fused("e2.w", P)
+        if w2 is not None:
+            if param_grads:
+                engine.linear_bwd(ctx, w2, dmulv, self._fused("e2.w", G), self._fused("e2.b", G), dx=dctx)
+            else:
+                ops.gemm(dmulv, w2, dctx)
+        elif param_grads:
             engine.linear_bwd(ctx, P["e2mu.weight"], dmu, G["e2mu.weight"], G["e2mu.bias"], dx=dctx)
             engine.linear_bwd(ctx, P["e2logvar.weight"], dlv, G["e2logvar.weight"], G["e2logvar.bias"], dx=dctx,
                               dx_beta=1.0)
