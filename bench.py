@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--z-loss", action="store_true", help="include the z-reconstruction pass (calc_z_loss=True)")
     ap.add_argument("--eager", action="store_true", help="issue the step kernel by kernel instead of replaying a hipGraph")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="single-GPU rehearsal of the data-parallel schedule: a one-rank RCCL group, collectives issued")
     args = ap.parse_args()
 
     import ldrs_amd  # noqa: F401
@@ -91,6 +93,10 @@ def main():
     from ldrs_amd.utils.functional import kld_coef, temp_coef
     from oracle import cgn_oracle as O  # synthetic inputs + the cpu_baseline leg only
 
+    if args.force_dp and args.gpus == 1 and "RANK" not in os.environ:
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29511")
+        torch.cuda.set_device(0)
+        torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1)
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
@@ -103,26 +109,40 @@ def main():
     ocfg = O.OracleConfig(**CFG2)
     torch.manual_seed(1234)  # identical replicas on every rank
     model = Controlled_Generation_Sentence(cfg, O.synthetic_word_embed(ocfg)).cuda()
-    if world > 1:
-        parallel.attach(model)
+    if world > 1 or args.force_dp:
+        parallel.attach(model, force=args.force_dp)
     eng = model.step_engine()
     opts = dict(disc=eng.new_optimizer("disc"), enc=eng.new_optimizer("enc"), gen=eng.new_optimizer("gen"))
     data, host_data = device_data(O, ocfg, BATCH, SEQ, 1234 + rank, dev)
     global_step = 5000
     kc, tau = kld_coef(global_step), temp_coef(global_step)
 
-    # N = 1: the step is captured once into a hipGraph (hip/graph.py) and replayed; its schedules and Adam step counts
-    # live in device memory, so every replay is a full, different training step. N > 1 (data parallel): eager, the
-    # RCCL all-reduces sit between the three optimizer phases.
-    use_graph = world == 1 and not args.eager
+    # The step is captured once into a hipGraph (hip/graph.py) and replayed; its schedules and Adam step counts live in
+    # device memory, so every replay is a full, different training step. N > 1 (data parallel): a chain of graph
+    # segments cut at the three gradient reductions, whose RCCL all-reduces are issued eagerly between the segments
+    # and overlap the next segment. CGN_DP_EAGER=1 (or a failed capture) falls back to the kernel-by-kernel step.
+    use_graph = not args.eager and not (world > 1 and os.environ.get("CGN_DP_EAGER") == "1")
 
     def eager_step():
         return eng.wake_sleep(opts, data, kc, tau, calc_z_loss=args.z_loss)
 
     if use_graph:
         from ldrs_amd.hip.graph import GraphedWakeSleep
-        graphed = GraphedWakeSleep(eng, opts, data, calc_z_loss=args.z_loss, warmup_kld=kc, warmup_tau=tau)
-
+        try:
+            graphed = GraphedWakeSleep(eng, opts, data, calc_z_loss=args.z_loss, warmup_kld=kc, warmup_tau=tau)
+        except Exception as e:  # noqa: BLE001 - report and fall back: the eager step is always available
+            if world == 1 and not args.force_dp:
+                raise
+            print("rank %d: segmented graph capture failed (%s: %s); running the eager step" %
+                  (rank, type(e).__name__, e), file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            use_graph = False
+    if world > 1:
+        # every rank must take the same path: one failed capture sends all ranks to the eager step
+        flag = torch.tensor([1.0 if use_graph else 0.0], device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        use_graph = bool(flag.item() > 0.5)
+    if use_graph:
         def step():
             return graphed(kc, tau, totals=False)
     else:
@@ -177,7 +197,8 @@ def main():
                                    "BASELINE configs[1]: vocab 20k, seq len 20, batch 64/GPU, emb 300, hidden 512, z 64, "
                                    "fp32, calc_z_loss=%s" % args.z_loss,
                        "global_batch": world * BATCH, "seq_len": SEQ, "parallelism": "dp%d" % world,
-                       "launch": "hipGraph replay" if use_graph else "eager"},
+                       "launch": ("hipGraph replay" if world == 1 and not args.force_dp else
+                                  "hipGraph segments + eager RCCL all-reduce") if use_graph else "eager"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                          "kernel": "gemm_kernel<128,true,true,true,false,2,16> (NT fp32 MFMA GEMM, 128x128 tile: the "
@@ -193,6 +214,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

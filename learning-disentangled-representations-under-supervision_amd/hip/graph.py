@@ -13,8 +13,11 @@ Nothing of the reference's semantics changes: the same kernels run in the same o
 step (tests/test_graph_gpu.py checks replayed training against eager training: losses 1e-6, weights 2e-6 — Adam's
 bias corrections are formed in double on the device instead of on the host).
 
-Data parallel runs (world_size > 1) stay eager this round: the bucketed RCCL all-reduce sits between graph segments
-and capturing it has not been validated on a multi-GPU node yet.
+Data parallel runs (world_size > 1) replay the step as a CHAIN of graph segments cut at the communication points of
+CGNStep's data-parallel schedule (step.py `_comm`): segment, RCCL all-reduce calls issued eagerly on RCCL's own stream,
+next segment. The collectives themselves are never captured (nothing here depends on RCCL being capturable); what the
+segmentation keeps is the one-launch-per-segment host cost and the overlap: the generator's gradient all-reduce
+travels while the encoder-backward segment runs, the encoder's while the generator's Adam segment runs.
 """
 import torch
 
@@ -24,13 +27,44 @@ INPUT_KEYS = ("x_labelled", "y_labelled", "x_generated", "c_generated", "mask_la
               "enc_char", "dec_word", "target", "c_uniform", "eps")
 
 
+class _SegmentRecorder:
+    """Captures one pass of the step into consecutive hipGraphs that share a memory pool; CGNStep._comm calls cut()."""
+
+    def __init__(self, thread_local):
+        self.segments = []  # [(graph, [actions run after it])]
+        self.pool = torch.cuda.graph_pool_handle()
+        self.g = None
+        # with a process group alive, its watchdog thread may touch HIP events while this thread captures
+        self.kw = dict(capture_error_mode="thread_local") if thread_local else {}
+
+    def begin(self):
+        self.g = torch.cuda.CUDAGraph()
+        self.g.capture_begin(pool=self.pool, **self.kw)
+
+    def cut(self, actions):
+        self.g.capture_end()
+        self.segments.append((self.g, actions))
+        self.begin()
+
+    def end(self):
+        self.g.capture_end()
+        self.segments.append((self.g, []))
+        self.g = None
+
+    def abort(self):
+        if self.g is not None:
+            try:
+                self.g.capture_end()
+            except Exception:
+                pass
+            self.g = None
+
+
 class GraphedWakeSleep:
     def __init__(self, eng, opts, data, calc_z_loss=False, overlap=True, warmup_kld=0.5, warmup_tau=1.0):
         """eng: CGNStep; opts: dict(disc, enc, gen) of AdamState; data: dict of device tensors giving the SHAPES of
         every later batch (their current contents are used for ONE real warm-up step, which trains the model like any
         other step)."""
-        if eng.world_size > 1:
-            raise RuntimeError("graph replay of the data-parallel step is not enabled: run the eager step")
         self.eng, self.opts, self.calc_z = eng, opts, calc_z_loss
         self.static = {k: data[k].clone() for k in INPUT_KEYS if data.get(k) is not None}
         self.B = self.static["enc_word"].shape[0]
@@ -56,8 +90,28 @@ class GraphedWakeSleep:
             torch.cuda.synchronize(eng.dev)
             ops.KEEP = []
             try:
-                with torch.cuda.graph(self.graph, stream=self.stream):
-                    self.out = self._run()
+                if eng.dp:
+                    import gc
+                    gc.collect()
+                    torch.cuda.empty_cache()
+                    rec = _SegmentRecorder(thread_local=torch.distributed.is_initialized())
+                    eng.recorder = rec
+                    try:
+                        with torch.cuda.stream(self.stream):
+                            rec.begin()
+                            try:
+                                self.out = self._run()
+                                rec.end()
+                            except BaseException:
+                                rec.abort()
+                                raise
+                    finally:
+                        eng.recorder = None
+                    self.segments = rec.segments
+                else:
+                    with torch.cuda.graph(self.graph, stream=self.stream):
+                        self.out = self._run()
+                    self.segments = [(self.graph, [])]
             finally:
                 self.keep, ops.KEEP = ops.KEEP, None  # temporaries of the captured step stay alive with the graph
         finally:
@@ -88,7 +142,10 @@ class GraphedWakeSleep:
         if data is not None:
             self.load(data)
         eng.set_step_scalars(kld_coeff, temperature, self.NT, self.B, self._slot())
-        self.graph.replay()
+        for g, actions in self.segments:
+            g.replay()
+            for kind, group in actions:
+                eng.do_comm(kind, group)
         self._bump_host_steps()
         d_losses, c, eg = self.out
         ce, kld, z_loss, c_loss = eg[:4]

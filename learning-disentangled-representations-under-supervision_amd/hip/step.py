@@ -26,10 +26,11 @@ def _new(shape, dev, dtype=torch.float32):
 
 
 class CGNStep:
-    def __init__(self, model, allreduce=None, world_size=1):
-        """model: Controlled_Generation_Sentence on a HIP device. allreduce(flat_grad_tensor) is called on each
-        optimizer group's gradient arena right before its Adam step (data parallelism); gradients are then scaled by
-        1/world_size inside the Adam kernel."""
+    def __init__(self, model, allreduce=None, world_size=1, force_dp=False):
+        """model: Controlled_Generation_Sentence on a HIP device. allreduce: parallel.BucketedAllReduce-like object
+        (begin(flat) -> handles, wait(handles)); each optimizer group's gradient arena is summed over the ranks between
+        its last gradient kernel and its Adam kernel (data parallelism), and scaled by 1/world_size inside the Adam
+        kernel. force_dp keeps that schedule on for world_size 1 (single-GPU rehearsal)."""
         self.model = model
         self.cfg = model.config
         named = dict(model.named_parameters())
@@ -59,12 +60,17 @@ class CGNStep:
             fused_enc["e2.w"] = ["e2mu.weight", "e2logvar.weight"]
             fused_enc["e2.b"] = ["e2mu.bias", "e2logvar.bias"]
         self.arenas = {k: ParamArena(v, dev, fused=fused_enc if k == "enc" else None) for k, v in groups.items()}
+        for k, a in self.arenas.items():
+            a.group = k
         self.P = {n: p.data for n, p in named.items()}
         self.G = {}
         for a in self.arenas.values():
             self.G.update(a.grads)
         self.allreduce = allreduce
         self.world_size = world_size
+        self.dp = allreduce is not None and (world_size > 1 or force_dp)
+        self._pending = {}     # optimizer group -> handles of its gradient all-reduce in flight
+        self.recorder = None   # hip/graph.py: while set, every communication point ends one graph segment
         cfg = self.cfg
         # Stream overlap (off by default: in eager mode the host, not the GPU, is the bound and every fork/join costs two
         # more host calls; hip/graph.py turns it on while capturing the step into a hipGraph). side(k) regions run on
@@ -126,11 +132,35 @@ class CGNStep:
         """Fresh Adam state for 'disc' | 'enc' | 'gen' (cgn.py:267, :1046-1047 create torch Adam objects likewise)."""
         return self.arenas[group].new_adam()
 
-    def _optim_step(self, state):
-        a = state.arena
-        if self.allreduce is not None and self.world_size > 1:
-            self.allreduce(a.g)
+    def _adam(self, state):
         state.apply(self.cfg.learning_rate, grad_scale=1.0 / self.world_size, dynamic=self.dynamic)
+
+    def _optim_step(self, state):
+        if self.dp:
+            g = state.arena.group
+            self._comm([("begin", g), ("wait", g)])
+        self._adam(state)
+
+    def do_comm(self, kind, group):
+        """Run one communication action now: ("begin", g) starts the all-reduce of group g's gradient arena on RCCL's
+        stream (ordered after the current stream), ("wait", g) orders the current stream after it."""
+        if kind == "begin":
+            self._pending[group] = self.allreduce.begin(self.arenas[group].g)
+        else:
+            self.allreduce.wait(self._pending.pop(group))
+
+    def _comm(self, actions):
+        """A communication point of the data-parallel schedule. Eager: run the actions. While a step is being recorded
+        (hip/graph.py) the side streams are joined, the current graph segment ends here and the actions are attached
+        to it: a replay launches the segment, then runs them, then launches the next segment."""
+        if not self.dp:
+            return
+        if self.recorder is not None:
+            self.join(0, 1)
+            self.recorder.cut(list(actions))
+            return
+        for kind, group in actions:
+            self.do_comm(kind, group)
 
     def _fused(self, name, table):
         """The stacked parameter (table is self.P) or gradient (self.G) view of an arena group, or None."""
@@ -179,8 +209,9 @@ class CGNStep:
         return c, p1
 
     def disc_train(self, opt, x_labelled, y_labelled, x_generated, c_generated, mask_labelled=None,
-                   mask_generated=None, train=True, capture=None):
-        """One discriminator step, model/cgn.py:269-341. Returns the 5-tuple of :341 as 1-element device tensors."""
+                   mask_generated=None, train=True, capture=None, step=True):
+        """One discriminator step, model/cgn.py:269-341. Returns the 5-tuple of :341 as 1-element device tensors.
+        step=False stops after the gradients (the data-parallel schedule reduces them and runs Adam later)."""
         cfg, P, G = self.cfg, self.P, self.G
         E = cfg.word_embed_size
         W, b = P["sentiment_discriminator.fc1.weight"], P["sentiment_discriminator.fc1.bias"]
@@ -204,7 +235,8 @@ class CGNStep:
         if train:
             if capture is not None:
                 capture["disc_grads"] = {n: g.clone() for n, g in self.arenas["disc"].grads.items()}
-            self._optim_step(opt)
+            if step:
+                self._optim_step(opt)
         ce_l, ce_g, ent = stats_all[0][0:1], stats_all[1][0:1], stats_all[1][1:2]
         gen_loss = ops.lincomb([(1.0, ce_g), (cfg.beta, ent)])  # :329
         total = ops.lincomb([(1.0, ce_l), (cfg.lambda_u, gen_loss)])  # :334
@@ -292,6 +324,28 @@ class CGNStep:
         encoder/generator step. opts: dict(disc, enc, gen); d: dict of device tensors (x_labelled, y_labelled,
         x_generated, c_generated, mask_labelled, mask_generated, enc_word, enc_char, dec_word, target, c_uniform, eps).
         With `overlap` the discriminator step and c inference run beside the encoder forward (they only meet at c)."""
+        if self.dp:
+            # Data-parallel schedule (SURVEY.md §8e), four segments with three reductions between them:
+            #   [disc gradients || embedding + encoder forward] -> reduce disc (1.5 MB) -> [disc Adam, c inference,
+            #   generator forward, losses, generator backward] -> START reduce gen (57 MB) -> [encoder backward, which
+            #   does not need it] -> wait gen, START reduce enc (38 MB) -> [gen Adam] -> wait enc -> [enc Adam]
+            with self.side(0):
+                d_losses = self.disc_train(opts["disc"], d["x_labelled"], d["y_labelled"], d["x_generated"],
+                                           d["c_generated"], d.get("mask_labelled"), d.get("mask_generated"), step=False)
+            c_box = []
+
+            def late_c():
+                self.join(0)
+                self._comm([("begin", "disc"), ("wait", "disc")])
+                self._adam(opts["disc"])
+                c_box.append(self.infer_c(d["enc_word"], d["c_uniform"])[0])
+                return c_box[0]
+
+            eg_losses = self.enc_gen_train((opts["enc"], opts["gen"]), d["enc_word"], d["enc_char"], d["dec_word"],
+                                           d["target"], late_c, d["eps"], kld_coeff, temperature,
+                                           calc_z_loss=calc_z_loss)
+            self.join(0, 1)
+            return d_losses, c_box[0], eg_losses
         with self.side(0):
             d_losses = self.disc_train(opts["disc"], d["x_labelled"], d["y_labelled"], d["x_generated"],
                                        d["c_generated"], d.get("mask_labelled"), d.get("mask_generated"))
@@ -332,6 +386,8 @@ class CGNStep:
         es = self._encoder_fwd(enc_in, B, L)
         mulv = es["mulv"]
         zc, std, kld = _new((B, Z + C), dev), _new((B, Z), dev), _new((1,), dev)
+        if callable(c_target):
+            c_target = c_target()  # data-parallel wake_sleep(): reduce + apply the discriminator gradients, then infer c
         self.join(0)  # wake_sleep(): the discriminator step and c inference ran beside the encoder forward
         cvec = c_target.reshape(B, C)
         ops.reparam_kld_fwd(mulv, eps, cvec, zc, std, kld)
@@ -450,7 +506,11 @@ class CGNStep:
             self.join(1)
             capture["g"] = dzc[:, :Z].clone()
             capture["gen_grads"] = {n: g.clone() for n, g in self.arenas["gen"].grads.items()}
-        if not joint:
+        if self.dp:
+            if not joint:
+                self.join(1)
+                self._comm([("begin", "gen")])  # travels while the encoder's backward pass runs
+        elif not joint:
             with self.side(1):  # the generator's Adam step follows its gradients; the encoder backward does not wait
                 self._optim_step(opts[1])  # cgn.py:1143
         # ---- encoder backward (cgn.py:1145-1149): kld_coef*KLD + z_out.backward(g) ---------------------------------
@@ -463,7 +523,19 @@ class CGNStep:
         self.join(1)
         if capture is not None:
             capture["enc_grads"] = {n: g.clone() for n, g in self.arenas["enc"].grads.items()}
-        self._optim_step(opts[0])  # cgn.py:1149
-        if joint:
-            self._optim_step(opts[1])  # initial VAE training: one optimizer over everything (cgn.py:623,645)
+        if self.dp:
+            if joint:  # initial VAE training: one optimizer over everything (cgn.py:623,645)
+                self._comm([("begin", "enc"), ("begin", "gen"), ("wait", "enc")])
+                self._adam(opts[0])
+                self._comm([("wait", "gen")])
+                self._adam(opts[1])
+            else:
+                self._comm([("wait", "gen"), ("begin", "enc")])
+                self._adam(opts[1])  # cgn.py:1143 (its update touches nothing the encoder backward read)
+                self._comm([("wait", "enc")])
+                self._adam(opts[0])  # cgn.py:1149
+        else:
+            self._optim_step(opts[0])  # cgn.py:1149
+            if joint:
+                self._optim_step(opts[1])  # initial VAE training: one optimizer over everything (cgn.py:623,645)
         return ce, kld, z_loss, c_loss, enc_loss, gen_loss

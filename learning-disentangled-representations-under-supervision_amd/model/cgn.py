@@ -53,6 +53,7 @@ class Controlled_Generation_Sentence(nn.Module):
         # data parallelism hooks (parallel.py sets them): all-reduce callable over a flat gradient arena + world size
         self._allreduce = None
         self._world_size = 1
+        self._force_dp = False
         self._step_engine = None
 
     # ------------------------------------------------------------------------------------------------------------
@@ -61,13 +62,15 @@ class Controlled_Generation_Sentence(nn.Module):
     def step_engine(self):
         eng = self._step_engine
         if eng is None or not eng.valid():
-            eng = CGNStep(self, allreduce=self._allreduce, world_size=self._world_size)
+            eng = CGNStep(self, allreduce=self._allreduce, world_size=self._world_size, force_dp=self._force_dp)
             self._step_engine = eng
         return eng
 
-    def set_data_parallel(self, allreduce, world_size):
-        """allreduce(flat_fp32_grad_tensor) must sum the tensor in place over all ranks (e.g. RCCL all_reduce)."""
-        self._allreduce, self._world_size = allreduce, int(world_size)
+    def set_data_parallel(self, allreduce, world_size, force=False):
+        """allreduce: parallel.BucketedAllReduce-like object (begin(flat) -> handles, wait(handles)) that sums a flat
+        fp32 gradient tensor in place over all ranks (RCCL all_reduce). force: keep the data-parallel schedule on for a
+        one-rank group."""
+        self._allreduce, self._world_size, self._force_dp = allreduce, int(world_size), bool(force)
         self._step_engine = None
 
     def compute_mahalabonis(self, mu1, mu2, std1, std2):

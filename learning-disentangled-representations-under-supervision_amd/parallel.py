@@ -6,8 +6,9 @@ The reference has no distributed code; every loss of the step is
 (§8e), so averaging per-rank gradients of equal-size shards equals one step over the concatenated batch.
 
 Buckets: xGMI is point-to-point, so a ring all-reduce is bound per link; a few large contiguous messages are used
-(BUCKET_BYTES) instead of one call per tensor. Buckets are issued asynchronously on RCCL's stream and waited for just
-before the Adam kernel, so the last GEMMs of the backward pass overlap the first buckets.
+(BUCKET_BYTES) instead of one call per tensor. A group's buckets are started (begin) as soon as its gradients are final
+and waited for (wait) right before its Adam kernel: the generator's 57 MB travel while the encoder's backward pass
+runs, the encoder's while the generator's Adam kernel runs (hip/step.py, hip/graph.py).
 """
 import torch
 import torch.distributed as dist
@@ -16,21 +17,36 @@ BUCKET_BYTES = 32 << 20
 
 
 class BucketedAllReduce:
-    def __init__(self, group=None, bucket_bytes=BUCKET_BYTES):
+    def __init__(self, group=None, bucket_bytes=BUCKET_BYTES, force=False):
+        """force: issue the collectives even in a one-rank group (single-GPU rehearsal of the data-parallel schedule)."""
         self.group = group
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self.force = force
 
-    def __call__(self, flat):
-        """Sum `flat` (1-D fp32 tensor) in place over all ranks."""
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
-            return
+    def _active(self):
+        return dist.is_initialized() and (self.force or dist.get_world_size(self.group) > 1)
+
+    def begin(self, flat):
+        """Start the in-place sum of `flat` (1-D fp32 tensor) over all ranks; returns the handles for wait().
+        On HIP the collectives run on RCCL's own stream, ordered after everything issued so far on the current
+        stream, so kernels launched between begin() and wait() overlap the transfer."""
+        if not self._active():
+            return []
         n = flat.numel()
         handles = []
         for lo in range(0, n, self.bucket_elems):
             hi = min(n, lo + self.bucket_elems)
             handles.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return handles
+
+    @staticmethod
+    def wait(handles):
         for h in handles:
             h.wait()  # on HIP: makes the current stream wait for the collective (no host block)
+
+    def __call__(self, flat):
+        """Sum `flat` in place over all ranks (begin + wait)."""
+        self.wait(self.begin(flat))
 
 
 def init_from_env(backend=None):
@@ -63,8 +79,9 @@ def shard_batch(tensors, rank, world):
     return out
 
 
-def attach(model, group=None):
-    """Make `model`'s fused step data-parallel over the initialised process group."""
+def attach(model, group=None, force=False):
+    """Make `model`'s fused step data-parallel over the initialised process group. force=True keeps the data-parallel
+    schedule (and its collectives) on even when the group has one rank."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    model.set_data_parallel(BucketedAllReduce(group), world)
+    model.set_data_parallel(BucketedAllReduce(group, force=force), world, force=force)
     return world

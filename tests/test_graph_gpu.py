@@ -78,3 +78,59 @@ def test_graph_rejects_other_shapes(dev):
     small = {k: v[:4] for k, v in data[0].items()}
     with pytest.raises(ValueError):
         g.load(small)
+
+
+@pytest.fixture(scope="module")
+def one_rank_group(dev):
+    """A one-rank RCCL process group: lets the data-parallel schedule (collectives included) run on a single MI355X."""
+    import socket
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    yield
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graphed,calc_z", [(False, False), (True, False), (True, True)])
+def test_data_parallel_schedule_one_rank_matches_plain_step(dev, one_rank_group, graphed, calc_z):
+    """The data-parallel schedule (disc gradients reduced before disc Adam and c inference, generator gradients
+    reduced beside the encoder backward, encoder gradients beside the generator's Adam) with real RCCL calls on a
+    one-rank group — eager, and as a chain of graph segments with the collectives between them — must train exactly
+    like the plain step (a one-rank sum is the identity)."""
+    from ldrs_amd import parallel
+    from ldrs_amd.hip.graph import GraphedWakeSleep
+    m_e, eng_e, opts_e, ocfg = _build(dev)
+    m_d, _, _, _ = _build(dev)
+    parallel.attach(m_d, force=True)
+    eng_d = m_d.step_engine()
+    assert eng_d.dp and not eng_e.dp
+    opts_d = dict(disc=eng_d.new_optimizer("disc"), enc=eng_d.new_optimizer("enc"), gen=eng_d.new_optimizer("gen"))
+    data = _batches(ocfg, dev, len(SCHED))
+    ref = []
+    for (kc, tau), d in zip(SCHED, data):
+        dl, c, eg = eng_e.wake_sleep(opts_e, d, kc, tau, calc_z_loss=calc_z)
+        ref.append([float(x) for x in dl] + [float(x) for x in eg[:4]] + [float(c.sum())])
+    got = []
+    if graphed:
+        g = GraphedWakeSleep(eng_d, opts_d, data[0], calc_z_loss=calc_z, warmup_kld=SCHED[0][0], warmup_tau=SCHED[0][1])
+        assert len(g.segments) == 5 and sum(len(a) for _, a in g.segments) == 6
+        for (kc, tau), d in zip(SCHED[1:], data[1:]):
+            dl, c, eg = g(kc, tau, d)
+            got.append([float(x) for x in dl] + [float(x) for x in eg[:4]] + [float(c.sum())])
+        ref = ref[1:]
+    else:
+        for (kc, tau), d in zip(SCHED, data):
+            dl, c, eg = eng_d.wake_sleep(opts_d, d, kc, tau, calc_z_loss=calc_z)
+            got.append([float(x) for x in dl] + [float(x) for x in eg[:4]] + [float(c.sum())])
+    torch.cuda.synchronize()
+    assert not eng_d._pending
+    for a, b in zip(ref, got):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 1e-6 * max(1.0, abs(x)), (a, b)
+    for (n, p), (_, q) in zip(m_e.named_parameters(), m_d.named_parameters()):
+        err = (p - q).abs().max().item() / max(p.abs().max().item(), 1e-12)
+        assert err <= 2e-6, (n, err)
