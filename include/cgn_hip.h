@@ -125,6 +125,19 @@ typedef struct cgn_lstm_fwd_seq {
 int cgn_lstm_seq_fwd_f32(void* stream, const cgn_lstm_fwd_seq* seqs /* host */, int32_t nseq, int32_t B, int32_t T,
                          int32_t H);
 
+/* Persistent form of the two recurrences: ONE launch runs all T timesteps with the workgroup's W_hh slice, c_t / dc_t
+ * held in registers; the workgroups sharing a batch tile hand h_t (dgates_t) over through write-through stores and a
+ * per-group arrival counter (csrc/lstm.hip). Replaces the same reference call sites as cgn_lstm_seq_fwd/bwd_f32
+ * (nn.LSTM at model/encoder.py:17-21,40 and model/generator.py:17-20,58), same buffers and results.
+ * cgn_lstm_persistent_query: *sync_bytes = size of the caller-owned, 16-byte aligned device scratch `sync_ws` the
+ * launch needs (zeroed by the library on the stream before each launch), or 0 when the shape is not eligible
+ * (H % 16, H <= 512, nseq * ceil(B/16) * H/16 workgroups <= CUs of the current device): use the step kernels then.
+ * After the stream has drained, word (sync_bytes/4 - 32) of sync_ws is non-zero iff a bounded wait ran out
+ * (results invalid); launches sharing one sync_ws must not overlap. */
+int cgn_lstm_persistent_query(int32_t nseq, int32_t B, int32_t T, int32_t H, int64_t* sync_bytes);
+int cgn_lstm_seq_fwd_persistent_f32(void* stream, const cgn_lstm_fwd_seq* seqs /* host */, int32_t nseq, int32_t B,
+                                    int32_t T, int32_t H, void* sync_ws, int64_t sync_ws_bytes);
+
 /* BPTT. dgates [B,T,4H] receives d(pre-activation gates); dW_ih/dW_hh/db/dX follow as GEMMs / column sums.
  * dh_ext: nullable gradient wrt the emitted h, element (b,t,j) at dh_ext[b*dh_bs + t*dh_ts + j];
  * dh_seed: nullable [B,H] gradient wrt the final hidden state; dc_state [B,H]: in = gradient wrt the final cell
@@ -143,6 +156,8 @@ typedef struct cgn_lstm_bwd_seq {
 
 int cgn_lstm_seq_bwd_f32(void* stream, const cgn_lstm_bwd_seq* seqs /* host */, int32_t nseq, int32_t B, int32_t T,
                          int32_t H);
+int cgn_lstm_seq_bwd_persistent_f32(void* stream, const cgn_lstm_bwd_seq* seqs /* host */, int32_t nseq, int32_t B,
+                                    int32_t T, int32_t H, void* sync_ws, int64_t sync_ws_bytes);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Convolution + max-over-time pooling helpers, shared by the text-CNN discriminator

@@ -280,6 +280,297 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_step_bwd_kernel(const BwdParams 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent recurrence: ONE launch runs all T timesteps.
+//
+// Same decomposition as the step kernels (workgroup = 16 batch rows x 16 hidden units, 8 waves split K), but the
+// workgroup's slice of W_hh (forward: 64 gate rows x H; backward: 16 rows of W_hhᵀ x 4H = 128 KB at H = 512) is loaded
+// ONCE into registers (64 VGPRs per lane) and stays there across timesteps; c_t (forward) and dc_t (backward) of the
+// workgroup's own 16x16 elements stay in registers too. What crosses workgroups per step is h_t (dgates_t): the
+// workgroups that share a batch tile form a GROUP, and only a group synchronises (never the grid):
+//   producer: h_t stored write-through (sc1), every storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, ONE
+//             lane adds 1 to the group's counter (agent-scope atomic);
+//   consumer: ONE lane polls the counter (relaxed sc1 loads, bounded) until NJ*step arrivals, workgroup barrier,
+//             then EVERY load of the handed-off rows is an sc1 buffer load (L2-served, never this CU's L1).
+// This is the all-sc1 hand-off of MI355X_MICROARCH.md (visibility table, first row): placement-independent, no
+// L1/L2 invalidate per step. Counters and the timeout word are zeroed by a memset node before each launch.
+// Residency: grid <= number of CUs (host check), 512-thread workgroups; every spin is bounded: a wait that runs out
+// raises the timeout word, which ends every other wait, so the grid always drains (results are then invalid and the
+// host-visible word says so).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr unsigned PERSIST_SPIN_LIMIT = 1u << 19;
+constexpr int SYNC_STRIDE = 32;  // u32 words per counter: one 128-byte line each
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bool group_wait(unsigned* cnt, unsigned target, unsigned* tmo) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        ++spins;
+        if (spins > PERSIST_SPIN_LIMIT ||
+            ((spins & 63u) == 0u && __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+    return true;
+}
+
+__device__ __forceinline__ f32x4 ld4_sc1(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16);  // aux 16 = sc1
+    return __builtin_bit_cast(f32x4, v);
+}
+
+__device__ __forceinline__ void st_sc1(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword ... sc1
+}
+
+// CPW: chunks (of 16 k) per wave held in registers; H <= 128 * CPW.
+template <int CPW>
+__global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_kernel(const FwdParams p, unsigned* sync) {
+    __shared__ float red[LSTM_NW][16][64];
+    __shared__ int s_ok;
+    const int B = p.B, T = p.T, H = p.H;
+    const int NJ = H / 16, NB = (B + 15) / 16;
+    const int wid = blockIdx.x;
+    const int seq = wid / (NB * NJ);
+    const int bt = (wid % (NB * NJ)) / NJ, jt = wid % NJ;
+    const FwdSeq& sq = p.s[seq];
+    unsigned* cnt = sync + (seq * NB + bt) * SYNC_STRIDE;
+    unsigned* tmo = sync + p.nseq * NB * SYNC_STRIDE;
+    const int j0 = jt * 16, b0 = bt * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, q = lane >> 4;
+    const int nchunks = H / 16;
+    const int cpw = (nchunks + LSTM_NW - 1) / LSTM_NW;  // <= CPW (host check)
+    const int c_beg = wave * cpw;
+
+    // this workgroup's W_hh rows (4 gates x 16 units), this wave's k range: registers for the whole sequence
+    const float* wrow = sq.w_hh + (long)(j0 + fr) * H;
+    const long gate_stride = (long)H * H;
+    f32x4 w[4][CPW];
+    int koff[CPW];
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+        const bool ok = (u < cpw) && (c_beg + u < nchunks);
+        const int kc = ok ? (c_beg + u) * 16 + q * 4 : 0;
+        koff[u] = kc * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = ld4(wrow + g * gate_stride + kc);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            w[g][u] = ok ? v : z;
+        }
+    }
+    const int bA = min(b0 + fr, B - 1);
+    const __amdgpu_buffer_rsrc_t hres =
+        __builtin_amdgcn_make_buffer_rsrc((void*)sq.hbuf, 0, B * (T + 1) * H * 4, 0x00020000);
+
+    // the cell-update element of this thread (waves 0..3): row (lane>>4)*4 + wave, unit lane&15 -- fixed for all t
+    const int er = wave & 3;
+    const int eb = b0 + (lane >> 4) * 4 + er, ej = j0 + (lane & 15);
+    const int ebc = min(eb, B - 1);
+    const bool evalid = (wave < 4) && (eb < B);
+    const int init_slot = sq.reverse ? T : 0;
+    float c_reg = sq.cbuf[((long)ebc * (T + 1) + init_slot) * H + ej];
+    float pre_e[4] = {0.f, 0.f, 0.f, 0.f};
+    if (sq.xg_extra) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre_e[g] = sq.xg_extra[(long)ebc * 4 * H + g * H + ej];
+    }
+
+    for (int step = 0; step < T; ++step) {
+        const int t = sq.reverse ? (T - 1 - step) : step;
+        const int slot_prev = sq.reverse ? t + 1 : t;
+        const int slot_out = sq.reverse ? t : t + 1;
+        float pre_x[4];
+        {
+            const float* xg = sq.xg + ((long)ebc * T + t) * 4 * H + ej;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre_x[g] = xg[g * H];
+        }
+        if (step > 0) {
+            if (threadIdx.x == 0) s_ok = group_wait(cnt, (unsigned)(NJ * step), tmo) ? 1 : 0;
+            __syncthreads();
+            if (!s_ok) break;  // workgroup-uniform
+        }
+        const int hoff = (bA * (T + 1) + slot_prev) * H * 4;
+        f32x4 a[CPW];
+#pragma unroll
+        for (int u = 0; u < CPW; ++u) a[u] = ld4_sc1(hres, hoff + koff[u]);
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < CPW; ++u) {  // chunks beyond this wave's range hold zero weights: no branch
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w[g][u][i], acc[g], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][g * 4 + r][lane] = acc[g][r];
+        __syncthreads();
+        if (evalid) {
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < LSTM_NW; ++wv) v += red[wv][g * 4 + er][lane];
+                pre[g] = v + pre_x[g] + pre_e[g];
+            }
+            const float ig = cgn_sigmoid(pre[0]);
+            const float fg = cgn_sigmoid(pre[1]);
+            const float gg = tanhf(pre[2]);
+            const float og = cgn_sigmoid(pre[3]);
+            const float cn = fg * c_reg + ig * gg;
+            const float hn = og * tanhf(cn);
+            c_reg = cn;
+            float* go = sq.gates + ((long)eb * T + t) * 4 * H;
+            go[ej] = ig;
+            go[H + ej] = fg;
+            go[2 * H + ej] = gg;
+            go[3 * H + ej] = og;
+            sq.cbuf[((long)eb * (T + 1) + slot_out) * H + ej] = cn;
+            st_sc1(sq.hbuf + ((long)eb * (T + 1) + slot_out) * H + ej, hn);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the arrival is signalled
+        __syncthreads();
+        if (threadIdx.x == 0 && step + 1 < T)
+            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// CPW: chunks (of 16 k over K = 4H) per wave held in registers; H <= 32 * CPW.
+template <int CPW>
+__global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdParams p, unsigned* sync) {
+    __shared__ float red[LSTM_NW][4][64];
+    __shared__ int s_ok;
+    const int B = p.B, T = p.T, H = p.H;
+    const int K = 4 * H;
+    const int NJ = H / 16, NB = (B + 15) / 16;
+    const int wid = blockIdx.x;
+    const int seq = wid / (NB * NJ);
+    const int bt = (wid % (NB * NJ)) / NJ, jt = wid % NJ;
+    const BwdSeq& sq = p.s[seq];
+    unsigned* cnt = sync + (seq * NB + bt) * SYNC_STRIDE;
+    unsigned* tmo = sync + p.nseq * NB * SYNC_STRIDE;
+    const int j0 = jt * 16, b0 = bt * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, q = lane >> 4;
+    const int nchunks = K / 16;
+    const int cpw = (nchunks + LSTM_NW - 1) / LSTM_NW;  // <= CPW (host check)
+    const int c_beg = wave * cpw;
+
+    const float* wrow = sq.w_hh_t + (long)(j0 + fr) * K;
+    f32x4 w[CPW];
+    int koff[CPW];
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+        const bool ok = (u < cpw) && (c_beg + u < nchunks);
+        const int kc = ok ? (c_beg + u) * 16 + q * 4 : 0;
+        koff[u] = kc * 4;
+        const f32x4 v = ld4(wrow + kc);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        w[u] = ok ? v : z;
+    }
+    const int bA = min(b0 + fr, B - 1);
+    const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void*)sq.dgates, 0, B * T * K * 4, 0x00020000);
+
+    const int er = wave & 3;
+    const int eb = b0 + (lane >> 4) * 4 + er, ej = j0 + (lane & 15);
+    const int ebc = min(eb, B - 1);
+    const bool evalid = (wave < 4) && (eb < B);
+    float dc_reg = sq.dc_state[(long)ebc * H + ej];
+    const float seed = sq.dh_seed ? sq.dh_seed[(long)ebc * H + ej] : 0.f;
+
+    for (int step = 0; step < T; ++step) {
+        const int t = sq.reverse ? step : (T - 1 - step);
+        const int t_next = sq.reverse ? t - 1 : t + 1;
+        const int slot_prev = sq.reverse ? t + 1 : t;
+        const int slot_out = sq.reverse ? t : t + 1;
+        // operands of the gate-gradient update (written by earlier kernels): requested before the wait
+        const float* gt = sq.gates + ((long)ebc * T + t) * K + ej;
+        const float ig = gt[0], fg = gt[H], gg = gt[2 * H], og = gt[3 * H];
+        const float cprev = sq.cbuf[((long)ebc * (T + 1) + slot_prev) * H + ej];
+        const float cout = sq.cbuf[((long)ebc * (T + 1) + slot_out) * H + ej];
+        const float dhx = sq.dh_ext ? sq.dh_ext[(long)ebc * sq.dh_bs + (long)t * sq.dh_ts + ej] : 0.f;
+
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (step > 0) {
+            if (threadIdx.x == 0) s_ok = group_wait(cnt, (unsigned)(NJ * step), tmo) ? 1 : 0;
+            __syncthreads();
+            if (!s_ok) break;  // workgroup-uniform
+            const int aoff = (bA * T + t_next) * K * 4;
+            f32x4 a[CPW];
+#pragma unroll
+            for (int u = 0; u < CPW; ++u) a[u] = ld4_sc1(dres, aoff + koff[u]);
+#pragma unroll
+            for (int u = 0; u < CPW; u += 2) {  // chunks beyond this wave's range hold zero weights: no branch
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w[u][i], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u + 1][i], w[u + 1][i], acc1, 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc0[r] + acc1[r];
+        __syncthreads();
+        if (evalid) {
+            float dh = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < LSTM_NW; ++wv) dh += red[wv][er][lane];
+            if (step == 0) dh += seed;
+            dh += dhx;
+            const float tc = tanhf(cout);
+            const float dc = dc_reg + dh * og * (1.f - tc * tc);
+            float* dg = sq.dgates + ((long)eb * T + t) * K;
+            st_sc1(dg + ej, dc * gg * ig * (1.f - ig));
+            st_sc1(dg + H + ej, dc * cprev * fg * (1.f - fg));
+            st_sc1(dg + 2 * H + ej, dc * ig * (1.f - gg * gg));
+            st_sc1(dg + 3 * H + ej, dh * tc * og * (1.f - og));
+            dc_reg = dc * fg;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0 && step + 1 < T)
+            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (evalid) sq.dc_state[(long)eb * H + ej] = dc_reg;
+}
+
+int g_num_cus[16] = {0};
+
+int device_cus() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+    if (g_num_cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        g_num_cus[dev] = n;
+    }
+    return g_num_cus[dev];
+}
+
+// shapes the persistent kernels take: whole 16-unit tiles, the register-resident W slice, one workgroup per CU at most
+bool persist_ok(int nseq, int B, int T, int H) {
+    if (nseq < 1 || nseq > LSTM_MAX_SEQ || B < 1 || T < 1 || H < 16 || H % 16 != 0 || H > 512) return false;
+    const long wgs = (long)nseq * cgn_cdiv(B, 16) * (H / 16);
+    if (wgs > device_cus()) return false;
+    if ((long)B * (T + 1) * H * 4 >= (1L << 31) || (long)B * T * 4 * H * 4 >= (1L << 31)) return false;
+    return true;
+}
+
+long persist_sync_bytes(int nseq, int B) { return ((long)nseq * cgn_cdiv(B, 16) + 1) * SYNC_STRIDE * 4; }
+
 }  // namespace
 
 extern "C" int cgn_lstm_seq_fwd_f32(void* stream, const cgn_lstm_fwd_seq* seqs, int32_t nseq, int32_t B, int32_t T,
@@ -322,6 +613,70 @@ extern "C" int cgn_lstm_seq_bwd_f32(void* stream, const cgn_lstm_bwd_seq* seqs, 
         p.step = step;
         hipLaunchKernelGGL(lstm_step_bwd_kernel, grid, dim3(LSTM_NT), 0, (hipStream_t)stream, p);
     }
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}
+
+extern "C" int cgn_lstm_persistent_query(int32_t nseq, int32_t B, int32_t T, int32_t H, int64_t* sync_bytes) {
+    CGN_CHECK_ARG(sync_bytes != nullptr);
+    if (!persist_ok(nseq, B, T, H)) {
+        *sync_bytes = 0;
+        return CGN_OK;
+    }
+    *sync_bytes = persist_sync_bytes(nseq, B);
+    return CGN_OK;
+}
+
+extern "C" int cgn_lstm_seq_fwd_persistent_f32(void* stream, const cgn_lstm_fwd_seq* seqs, int32_t nseq, int32_t B,
+                                               int32_t T, int32_t H, void* sync_ws, int64_t sync_ws_bytes) {
+    CGN_CHECK_ARG(seqs && nseq >= 1 && nseq <= LSTM_MAX_SEQ);
+    CGN_CHECK_ARG(B >= 0 && T >= 0 && H > 0);
+    if (B == 0 || T == 0) return CGN_OK;
+    CGN_CHECK_ARG(persist_ok(nseq, B, T, H));
+    const long need = persist_sync_bytes(nseq, B);
+    CGN_CHECK_ARG(sync_ws && sync_ws_bytes >= need && ((uintptr_t)sync_ws % 16 == 0));
+    FwdParams p;
+    for (int i = 0; i < nseq; ++i) {
+        const cgn_lstm_fwd_seq& s = seqs[i];
+        CGN_CHECK_ARG(s.xg && s.w_hh && s.hbuf && s.cbuf && s.gates);
+        CGN_CHECK_ARG(((uintptr_t)s.hbuf % 16 == 0) && ((uintptr_t)s.w_hh % 16 == 0));
+        p.s[i] = {s.xg, s.xg_extra, s.w_hh, s.hbuf, s.cbuf, s.gates, s.reverse};
+    }
+    p.B = B; p.T = T; p.H = H; p.nseq = nseq; p.step = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(sync_ws, 0, (size_t)need, st) != hipSuccess) return CGN_ERR_HIP_BASE + (int)hipGetLastError();
+    dim3 grid(nseq * cgn_cdiv(B, 16) * (H / 16));
+    if (H <= 256)
+        hipLaunchKernelGGL((lstm_persist_fwd_kernel<2>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws);
+    else
+        hipLaunchKernelGGL((lstm_persist_fwd_kernel<4>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws);
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}
+
+extern "C" int cgn_lstm_seq_bwd_persistent_f32(void* stream, const cgn_lstm_bwd_seq* seqs, int32_t nseq, int32_t B,
+                                               int32_t T, int32_t H, void* sync_ws, int64_t sync_ws_bytes) {
+    CGN_CHECK_ARG(seqs && nseq >= 1 && nseq <= LSTM_MAX_SEQ);
+    CGN_CHECK_ARG(B >= 0 && T >= 0 && H > 0);
+    if (B == 0 || T == 0) return CGN_OK;
+    CGN_CHECK_ARG(persist_ok(nseq, B, T, H));
+    const long need = persist_sync_bytes(nseq, B);
+    CGN_CHECK_ARG(sync_ws && sync_ws_bytes >= need && ((uintptr_t)sync_ws % 16 == 0));
+    BwdParams p;
+    for (int i = 0; i < nseq; ++i) {
+        const cgn_lstm_bwd_seq& s = seqs[i];
+        CGN_CHECK_ARG(s.w_hh_t && s.cbuf && s.gates && s.dgates && s.dc_state);
+        CGN_CHECK_ARG(((uintptr_t)s.dgates % 16 == 0) && ((uintptr_t)s.w_hh_t % 16 == 0));
+        p.s[i] = {s.w_hh_t, s.cbuf, s.gates, s.dh_ext, s.dh_seed, s.dgates, s.dc_state, s.dh_bs, s.dh_ts, s.reverse};
+    }
+    p.B = B; p.T = T; p.H = H; p.nseq = nseq; p.step = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(sync_ws, 0, (size_t)need, st) != hipSuccess) return CGN_ERR_HIP_BASE + (int)hipGetLastError();
+    dim3 grid(nseq * cgn_cdiv(B, 16) * (H / 16));
+    if (H <= 256)
+        hipLaunchKernelGGL((lstm_persist_bwd_kernel<8>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws);
+    else
+        hipLaunchKernelGGL((lstm_persist_bwd_kernel<16>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws);
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }

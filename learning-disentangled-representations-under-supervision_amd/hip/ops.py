@@ -470,6 +470,42 @@ def embedding_bwd(idx, dx, dtable, beta=0.0):
     _call("cgn_embedding_bwd_f32", dx.device, _ptr(idx), _ptr(dx), n, V, E, beta, _ptr(dtable), _ptr(ws), ws.numel() * 4)
 
 
+# Persistent LSTM launches (one launch per sequence pass, csrc/lstm.hip) need a small zeroed scratch for their arrival
+# counters: one per (device, stream), like the split-K workspace. LSTM_PERSISTENT=False (or CGN_LSTM_PERSISTENT=0)
+# forces the one-launch-per-timestep kernels, which take every shape.
+import os as _os
+LSTM_PERSISTENT = _os.environ.get("CGN_LSTM_PERSISTENT", "1") != "0"
+_lstm_sync = {}
+LSTM_SYNC_BYTES = 64 << 10
+
+
+def _lstm_sync_ws(device):
+    idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    ws = _lstm_sync.get(key)
+    if ws is None:
+        with torch.cuda.stream(torch.cuda.default_stream(idx)):
+            ws = torch.zeros(LSTM_SYNC_BYTES // 4, dtype=torch.int32, device=torch.device("cuda", idx))
+        _lstm_sync[key] = ws
+    return ws
+
+
+def lstm_persistent_bytes(nseq, B, T, H, dev):
+    """Scratch bytes a persistent launch of this shape needs on `dev`, 0 = not eligible (use the step kernels)."""
+    if not LSTM_PERSISTENT:
+        return 0
+    n = C.c_int64(0)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().cgn_lstm_persistent_query(nseq, B, T, H, C.byref(n)), "cgn_lstm_persistent_query")
+    return n.value if n.value <= LSTM_SYNC_BYTES else 0
+
+
+def lstm_timeout_word(dev, nseq, B, T, H):
+    """The timeout word of the last persistent launch of this shape on the current stream (0 = every wait was met)."""
+    n = lstm_persistent_bytes(nseq, B, T, H, dev)
+    return int(_lstm_sync_ws(dev)[n // 4 - 32].item()) if n else 0
+
+
 def lstm_seq_fwd(seqs, B, T, H):
     """seqs: list of dicts(xg, xg_extra=None, w_hh, hbuf, cbuf, gates, reverse)."""
     arr = (_lib.LstmFwdSeq * len(seqs))()
@@ -487,7 +523,12 @@ def lstm_seq_fwd(seqs, B, T, H):
             s["w_hh"].data_ptr()
         arr[i].hbuf, arr[i].cbuf, arr[i].gates = s["hbuf"].data_ptr(), s["cbuf"].data_ptr(), s["gates"].data_ptr()
         arr[i].reverse = 1 if s.get("reverse") else 0
-    _call("cgn_lstm_seq_fwd_f32", dev, arr, len(seqs), B, T, H)
+    nb = lstm_persistent_bytes(len(seqs), B, T, H, dev)
+    if nb:
+        ws = _lstm_sync_ws(dev)
+        _call("cgn_lstm_seq_fwd_persistent_f32", dev, arr, len(seqs), B, T, H, _ptr(ws), ws.numel() * 4)
+    else:
+        _call("cgn_lstm_seq_fwd_f32", dev, arr, len(seqs), B, T, H)
 
 
 def lstm_seq_bwd(seqs, B, T, H):
@@ -514,7 +555,12 @@ def lstm_seq_bwd(seqs, B, T, H):
         arr[i].dh_seed = seed.data_ptr() if seed is not None else None
         arr[i].dgates, arr[i].dc_state = s["dgates"].data_ptr(), s["dc_state"].data_ptr()
         arr[i].reverse = 1 if s.get("reverse") else 0
-    _call("cgn_lstm_seq_bwd_f32", dev, arr, len(seqs), B, T, H)
+    nb = lstm_persistent_bytes(len(seqs), B, T, H, dev)
+    if nb:
+        ws = _lstm_sync_ws(dev)
+        _call("cgn_lstm_seq_bwd_persistent_f32", dev, arr, len(seqs), B, T, H, _ptr(ws), ws.numel() * 4)
+    else:
+        _call("cgn_lstm_seq_bwd_f32", dev, arr, len(seqs), B, T, H)
 
 
 def lincomb(terms, out=None):

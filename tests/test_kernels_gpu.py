@@ -27,9 +27,18 @@ def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
 
-@pytest.mark.parametrize("B,T,H,Din,bidir", [(5, 4, 16, 12, True), (17, 6, 36, 23, False), (64, 3, 512, 40, True)])
-def test_lstm_fwd_bwd(dev, B, T, H, Din, bidir):
+@pytest.mark.parametrize("persistent", [False, True])
+@pytest.mark.parametrize("B,T,H,Din,bidir", [(5, 4, 16, 12, True), (17, 6, 36, 23, False), (64, 3, 512, 40, True),
+                                             (33, 7, 48, 20, True), (64, 21, 512, 24, False), (32, 15, 256, 24, True),
+                                             (64, 20, 512, 24, True)])
+def test_lstm_fwd_bwd(dev, B, T, H, Din, bidir, persistent, monkeypatch):
+    """persistent=True: the one-launch recurrence (register-resident W_hh, per-batch-tile hand-off of h_t) where the
+    shape is eligible; False: one launch per timestep. Both against torch.nn.LSTM in fp64."""
     engine, ops = _mods()
+    monkeypatch.setattr(ops, "LSTM_PERSISTENT", persistent)
+    nseq = 2 if bidir else 1
+    eligible = ops.lstm_persistent_bytes(nseq, B, T, H, dev) > 0
+    assert eligible == (persistent and H % 16 == 0 and H <= 512)
     torch.manual_seed(B + T + H)
     ref = torch.nn.LSTM(Din, H, 1, batch_first=True, bidirectional=bidir).double()
     x = rnd(B, T, Din, seed=1).double().requires_grad_(True)
@@ -49,6 +58,7 @@ def test_lstm_fwd_bwd(dev, B, T, H, Din, bidir):
         s.set_initial()
         seqs.append(s)
     engine.lstm_run_fwd(seqs, [P["weight_hh_l0" + sfx] for sfx, _ in dirs])
+    assert ops.lstm_timeout_word(dev, nseq, B, T, H) == 0
     for di, (s, (sfx, rev)) in enumerate(zip(seqs, dirs)):
         hout = s.hbuf[:, :T] if rev else s.hbuf[:, 1:]
         assert rel(hout, out[:, :, di * H:(di + 1) * H]) < TOL
@@ -60,6 +70,7 @@ def test_lstm_fwd_bwd(dev, B, T, H, Din, bidir):
         exts.append((e, T * H, H))
         dcs.append(w_c[di].float().contiguous().to(dev))
     dgs = engine.lstm_run_bwd(seqs, [P["weight_hh_l0" + sfx] for sfx, _ in dirs], exts, [None] * len(dirs), dcs)
+    assert ops.lstm_timeout_word(dev, nseq, B, T, H) == 0
     dx = torch.zeros(B * T, Din, device=dev)
     for di, (s, (sfx, rev)) in enumerate(zip(seqs, dirs)):
         G = {k: torch.full_like(P[k + sfx], float("nan")) for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0",
