@@ -24,11 +24,16 @@ __global__ __launch_bounds__(256) void act_maxpool_kernel(const float* __restric
         const float* p = conv + (long)b * P * Co + co;
         float best = p[0];
         int bi = 0;
-        for (int t = 1; t < P; ++t) {
-            const float v = p[(long)t * Co];
-            if (v > best) {
-                best = v;
-                bi = t;
+        for (int t0 = 1; t0 < P; t0 += 8) {  // 8 positions of loads in flight; first maximum wins, as in torch
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(long)min(t0 + u, P - 1) * Co];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (t0 + u < P && v[u] > best) {
+                    best = v[u];
+                    bi = t0 + u;
+                }
             }
         }
         if (act == ACT_TANH) {
@@ -61,8 +66,12 @@ __device__ __forceinline__ float pooled_grad(const ConvWidths& w, const float* d
 
 // dX[b, t, e] = sum over (width, map) whose kept window covers t of g[b,map] * W[map][t - t0][e].
 // One wave owns 64 consecutive outputs (t,e) of one sentence (e fastest => coalesced weight reads) and walks all
-// maps; the (argmax, gradient) pairs of 64 maps are loaded one per lane and broadcast with v_readlane, so the inner
-// loop has no dependent global loads. Every output element is owned by exactly one lane: no atomics, fixed order.
+// maps; the (argmax, gradient) pairs of 64 maps are loaded one per lane and broadcast with v_readlane. The walk is
+// BRANCH-FREE in batches of DXU maps: every lane issues DXU weight loads on clamped addresses before the first one is
+// consumed and a miss contributes an exact 0 (a branch per map made every load wait for the one before it: the kernel
+// was pure L2 latency, 124 us for the char-TDNN). Every output element is owned by exactly one lane: no atomics, fixed
+// summation order.
+constexpr int DXU = 16;
 __global__ __launch_bounds__(256) void conv_bwd_dx_kernel(const ConvWidths w, const float* __restrict__ dfeat,
                                                           const float* __restrict__ feat,
                                                           const int32_t* __restrict__ arg, int L, int E,
@@ -72,33 +81,43 @@ __global__ __launch_bounds__(256) void conv_bwd_dx_kernel(const ConvWidths w, co
     const int o = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;  // output index within the sentence
     const bool live = o < L * E;
     const int t = live ? o / E : 0, e = live ? o % E : 0;
-    // wave-uniform bounds on t (lanes are consecutive outputs)
     const int o_first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
-    if (o_first >= L * E) return;
-    const int t_lo = o_first / E, t_hi = min(L * E - 1, o_first + 63) / E;
+    if (o_first >= L * E) return;  // wave-uniform
     float acc = 0.f;
     for (int wi = 0; wi < w.n; ++wi) {
         const int Kw = w.K[wi], Co = w.Co[wi];
         const float* Wb = w.W[wi];
+        const int KE = Kw * E;
+        // this lane's offset inside a map's window for k = 0, and the step per k
+        const int e_off = (w.layout == 0) ? e : e * Kw;
+        const int k_step = (w.layout == 0) ? E : 1;
         for (int c0 = 0; c0 < Co; c0 += 64) {
-            int my_t0 = -1;
+            int my_t0 = -(1 << 20);  // a window that covers nothing
             float my_g = 0.f;
             if (c0 + lane < Co) {
                 const long fi = (long)b * w.F + w.col0[wi] + c0 + lane;
-                my_t0 = arg[fi];
-                if (my_t0 >= 0 && my_t0 + Kw <= L) my_g = pooled_grad(w, dfeat, feat, fi);
-                else my_t0 = -1;
+                const int t0 = arg[fi];
+                if (t0 >= 0 && t0 + Kw <= L) {
+                    my_t0 = t0;
+                    my_g = pooled_grad(w, dfeat, feat, fi);
+                }
             }
             const int nc = min(64, Co - c0);
-            for (int c = 0; c < nc; ++c) {
-                const int t0 = __builtin_amdgcn_readlane(my_t0, c);
-                if (t0 < 0 || t0 > t_hi || t0 + Kw <= t_lo) continue;  // scalar branch: window misses this wave
-                const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_g), c));
-                const int k = t - t0;
-                if (live && k >= 0 && k < Kw) {
-                    const float* wr = Wb + (long)(c0 + c) * Kw * E;
-                    acc += g * ((w.layout == 0) ? wr[k * E + e] : wr[e * Kw + k]);
+            for (int c = 0; c < nc; c += DXU) {
+                float wv[DXU], gv[DXU];
+#pragma unroll
+                for (int u = 0; u < DXU; ++u) {
+                    const int cc = min(c + u, nc - 1);
+                    const int t0 = __builtin_amdgcn_readlane(my_t0, cc);
+                    const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_g), cc));
+                    const int k = t - t0;
+                    const bool hit = live && (c + u < nc) && k >= 0 && k < Kw;
+                    const int off = hit ? e_off + k * k_step : 0;
+                    wv[u] = Wb[(long)(c0 + cc) * KE + off];
+                    gv[u] = hit ? g : 0.f;
                 }
+#pragma unroll
+                for (int u = 0; u < DXU; ++u) acc += gv[u] * wv[u];
             }
         }
     }
@@ -107,7 +126,10 @@ __global__ __launch_bounds__(256) void conv_bwd_dx_kernel(const ConvWidths w, co
 
 // dW[map][window element] (+)= sum_b g[b,map] * x[b, t0(b,map) + k, e];  db[map] (+)= sum_b g[b,map].
 // Workgroup = 64 window elements of one map; its 4 waves split the batch four ways and are summed through LDS in
-// fixed order. (t0, g) of 64 sentences are loaded one per lane and broadcast, so x loads pipeline freely.
+// fixed order. (t0, g) of 64 sentences are loaded one per lane and broadcast; the x loads of DWU sentences are issued
+// together (independent addresses) before any is consumed, so the walk over the batch is not one L2 round trip per
+// sentence.
+constexpr int DWU = 16;
 __global__ __launch_bounds__(256) void conv_bwd_dw_kernel(const ConvWidths w, const float* __restrict__ dfeat,
                                                           const float* __restrict__ feat, const int32_t* __restrict__ arg,
                                                           const float* __restrict__ x, long sent_stride, int B, int L,
@@ -121,6 +143,7 @@ __global__ __launch_bounds__(256) void conv_bwd_dw_kernel(const ConvWidths w, co
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;  // window element, order (k, e)
     const bool live = i < KE;
+    const int il = live ? i : 0;
     const int per = (B + 3) / 4;
     const int b_beg = wave * per, b_end = min(B, b_beg + per);
     float acc = 0.f, bsum = 0.f;
@@ -136,11 +159,21 @@ __global__ __launch_bounds__(256) void conv_bwd_dw_kernel(const ConvWidths w, co
             }
         }
         const int nb = min(64, b_end - bb);
-        for (int c = 0; c < nb; ++c) {
-            const int t0 = __builtin_amdgcn_readlane(my_t0, c);
-            const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_g), c));
-            bsum += g;
-            if (live) acc += g * x[(long)(bb + c) * sent_stride + (long)t0 * E + i];  // g == 0 for closed gates
+        for (int c = 0; c < nb; c += DWU) {
+            float xv[DWU], gv[DWU];
+#pragma unroll
+            for (int u = 0; u < DWU; ++u) {
+                const int cc = min(c + u, nb - 1);
+                const int t0 = __builtin_amdgcn_readlane(my_t0, cc);
+                const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_g), cc));
+                gv[u] = (c + u < nb) ? g : 0.f;  // g == 0 for closed gates
+                xv[u] = x[(long)(bb + cc) * sent_stride + (long)t0 * E + il];
+            }
+#pragma unroll
+            for (int u = 0; u < DWU; ++u) {
+                bsum += gv[u];
+                acc += gv[u] * xv[u];
+            }
         }
     }
     red[wave][lane] = acc;

@@ -251,11 +251,24 @@ __global__ __launch_bounds__(DH_NT) void disc_head_kernel(const float* __restric
     float ce_acc = 0.f, ent_acc = 0.f;
     for (int b = wave; b < B; b += DH_NT / 64) {
         float s0 = 0.f, s1 = 0.f;
-        for (int f = lane; f < F; f += 64) {
-            float x = feat[(long)b * ldf + f];
-            if (mask) x *= mask[(long)b * F + f];
-            s0 += x * W[f];
-            s1 += x * W[F + f];
+        // batches of 8 chunks: all loads of a batch are issued (clamped addresses) before the first is consumed
+        for (int f0 = 0; f0 < F; f0 += 512) {
+            float xv[8], mv[8], w0v[8], w1v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int f = f0 + u * 64 + lane;
+                const int fc = f < F ? f : 0;
+                xv[u] = feat[(long)b * ldf + fc];
+                mv[u] = mask ? mask[(long)b * F + fc] : 1.f;
+                w0v[u] = W[fc];
+                w1v[u] = W[F + fc];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float x = (f0 + u * 64 + lane < F) ? xv[u] * mv[u] : 0.f;
+                s0 += x * w0v[u];
+                s1 += x * w1v[u];
+            }
         }
         s0 = wave_sum(s0) + bias[0];
         s1 = wave_sum(s1) + bias[1];
@@ -303,13 +316,25 @@ __global__ __launch_bounds__(PW_NT) void disc_head_bwd_kernel(const float* __res
     if (f < F) {
         float a0 = 0.f, a1 = 0.f;
         const float w0 = W[f], w1 = W[F + f];
-        for (int b = 0; b < B; ++b) {
-            const float mk = mask ? mask[(long)b * F + f] : 1.f;
-            const float x = feat[(long)b * ldf + f] * mk;
-            const float d0 = dlogits[b * 2], d1 = dlogits[b * 2 + 1];
-            a0 += d0 * x;
-            a1 += d1 * x;
-            if (dfeat) dfeat[(long)b * F + f] = (d0 * w0 + d1 * w1) * mk;
+        for (int b0 = 0; b0 < B; b0 += 8) {  // 8 rows of loads in flight (the walk was one L2 round trip per row)
+            float mk[8], xv[8], d0[8], d1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = min(b0 + u, B - 1);
+                mk[u] = mask ? mask[(long)b * F + f] : 1.f;
+                xv[u] = feat[(long)b * ldf + f];
+                d0[u] = dlogits[b * 2];
+                d1[u] = dlogits[b * 2 + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (b0 + u < B) {
+                    const float x = xv[u] * mk[u];
+                    a0 += d0[u] * x;
+                    a1 += d1[u] * x;
+                    if (dfeat) dfeat[(long)(b0 + u) * F + f] = (d0[u] * w0 + d1[u] * w1) * mk[u];
+                }
+            }
         }
         if (dW) {
             dW[f] = (beta != 0.f) ? a0 + beta * dW[f] : a0;
