@@ -110,7 +110,8 @@ int cgn_softmax_nll_fwd_f32(void* stream, const float* logits, int64_t ld, const
  * up to 4 independent sequences — e.g. the encoder's two directions — per launch). Layouts (batch-major fp32):
  *   xg [B,T,4H] gate order i,f,g,o · hbuf/cbuf [B,T+1,H]: forward sequences keep the initial state in slot 0 and
  *   the state after time t in slot t+1; reverse sequences keep the initial state in slot T and time t in slot t ·
- *   gates [B,T,4H] activated gates (saved for backward). The caller initialises the initial-state slots. H % 4 == 0.
+ *   gates [B,T,4H] activated gates (saved for backward). The caller initialises the initial-state slots unless
+ *   init_zero is set. H % 4 == 0.
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct cgn_lstm_fwd_seq {
     const float* xg;
@@ -120,6 +121,7 @@ typedef struct cgn_lstm_fwd_seq {
     float* cbuf;
     float* gates;
     int32_t reverse;
+    int32_t init_zero; /* 1: zero initial state (nn.LSTM called without (h0,c0)); the library zeroes the initial slots */
 } cgn_lstm_fwd_seq;
 
 int cgn_lstm_seq_fwd_f32(void* stream, const cgn_lstm_fwd_seq* seqs /* host */, int32_t nseq, int32_t B, int32_t T,
@@ -143,7 +145,8 @@ int cgn_lstm_seq_fwd_persistent_f32(void* stream, const cgn_lstm_fwd_seq* seqs /
  * dh_seed: nullable [B,H] gradient wrt the final hidden state; dc_state [B,H]: in = gradient wrt the final cell
  * state (the encoder's context, encoder.py:43-46), out = gradient wrt the initial cell state. */
 typedef struct cgn_lstm_bwd_seq {
-    const float* w_hh_t; /* [H,4H] = W_hhᵀ (cgn_transpose_f32) */
+    const float* w_hh_t; /* [H,4H] = W_hhᵀ (cgn_transpose_f32); the persistent form takes w_hh instead when given */
+    const float* w_hh;   /* nullable [4H,H]: untransposed weight (persistent form only) */
     const float* cbuf;
     const float* gates;
     const float* dh_ext;

@@ -36,6 +36,7 @@ struct FwdSeq {
     float* cbuf;
     float* gates;
     int reverse;
+    int init_zero;
 };
 struct FwdParams {
     FwdSeq s[LSTM_MAX_SEQ];
@@ -44,6 +45,7 @@ struct FwdParams {
 
 struct BwdSeq {
     const float* w_hh_t;
+    const float* w_hh;
     const float* cbuf;
     const float* gates;
     const float* dh_ext;
@@ -374,7 +376,17 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_kernel(const FwdPara
     const int ebc = min(eb, B - 1);
     const bool evalid = (wave < 4) && (eb < B);
     const int init_slot = sq.reverse ? T : 0;
-    float c_reg = sq.cbuf[((long)ebc * (T + 1) + init_slot) * H + ej];
+    float c_reg = 0.f;
+    if (sq.init_zero) {
+        // zero initial state (nn.LSTM without (h0, c0)): nothing is read; the slots are written for the later readers
+        // of the history buffers (dW_hh's h_{t-1} operand, the backward pass's c_{t-1})
+        if (evalid) {
+            sq.hbuf[((long)eb * (T + 1) + init_slot) * H + ej] = 0.f;
+            sq.cbuf[((long)eb * (T + 1) + init_slot) * H + ej] = 0.f;
+        }
+    } else {
+        c_reg = sq.cbuf[((long)ebc * (T + 1) + init_slot) * H + ej];
+    }
     float pre_e[4] = {0.f, 0.f, 0.f, 0.f};
     if (sq.xg_extra) {
 #pragma unroll
@@ -396,20 +408,22 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_kernel(const FwdPara
             __syncthreads();
             if (!s_ok) break;  // workgroup-uniform
         }
-        const int hoff = (bA * (T + 1) + slot_prev) * H * 4;
-        f32x4 a[CPW];
-#pragma unroll
-        for (int u = 0; u < CPW; ++u) a[u] = ld4_sc1(hres, hoff + koff[u]);
         f32x4 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = {0.f, 0.f, 0.f, 0.f};
+        if (step > 0 || !sq.init_zero) {  // uniform: h_{-1} = 0 contributes nothing
+            const int hoff = (bA * (T + 1) + slot_prev) * H * 4;
+            f32x4 a[CPW];
 #pragma unroll
-        for (int u = 0; u < CPW; ++u) {  // chunks beyond this wave's range hold zero weights: no branch
+            for (int u = 0; u < CPW; ++u) a[u] = ld4_sc1(hres, hoff + koff[u]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int u = 0; u < CPW; ++u) {  // chunks beyond this wave's range hold zero weights: no branch
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w[g][u][i], acc[g], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w[g][u][i], acc[g], 0, 0, 0);
+                }
             }
         }
 #pragma unroll
@@ -469,7 +483,8 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdPara
     const int cpw = (nchunks + LSTM_NW - 1) / LSTM_NW;  // <= CPW (host check)
     const int c_beg = wave * cpw;
 
-    const float* wrow = sq.w_hh_t + (long)(j0 + fr) * K;
+    // B operand = W_hhᵀ rows (j0 + fr), this wave's k range. Loaded once, so the untransposed [4H,H] weight serves as
+    // well (16 lanes = 64 contiguous bytes per k) and the caller needs no transposed copy.
     f32x4 w[CPW];
     int koff[CPW];
 #pragma unroll
@@ -477,7 +492,13 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdPara
         const bool ok = (u < cpw) && (c_beg + u < nchunks);
         const int kc = ok ? (c_beg + u) * 16 + q * 4 : 0;
         koff[u] = kc * 4;
-        const f32x4 v = ld4(wrow + kc);
+        f32x4 v;
+        if (sq.w_hh) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = sq.w_hh[(long)(kc + i) * H + j0 + fr];
+        } else {
+            v = ld4(sq.w_hh_t + (long)(j0 + fr) * K + kc);
+        }
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         w[u] = ok ? v : z;
     }
@@ -583,7 +604,15 @@ extern "C" int cgn_lstm_seq_fwd_f32(void* stream, const cgn_lstm_fwd_seq* seqs, 
         const cgn_lstm_fwd_seq& s = seqs[i];
         CGN_CHECK_ARG(s.xg && s.w_hh && s.hbuf && s.cbuf && s.gates);
         CGN_CHECK_ARG(((uintptr_t)s.hbuf % 16 == 0) && ((uintptr_t)s.w_hh % 16 == 0));
-        p.s[i] = {s.xg, s.xg_extra, s.w_hh, s.hbuf, s.cbuf, s.gates, s.reverse};
+        p.s[i] = {s.xg, s.xg_extra, s.w_hh, s.hbuf, s.cbuf, s.gates, s.reverse, s.init_zero};
+        if (s.init_zero) {  // the step kernels read the initial-state slots: zero them here (strided [B,H] blocks)
+            const size_t off = (size_t)(s.reverse ? T : 0) * H, pitch = (size_t)(T + 1) * H * sizeof(float);
+            if (hipMemset2DAsync(s.hbuf + off, pitch, 0, (size_t)H * sizeof(float), (size_t)B, (hipStream_t)stream) !=
+                    hipSuccess ||
+                hipMemset2DAsync(s.cbuf + off, pitch, 0, (size_t)H * sizeof(float), (size_t)B, (hipStream_t)stream) !=
+                    hipSuccess)
+                return CGN_ERR_HIP_BASE + (int)hipGetLastError();
+        }
     }
     p.B = B; p.T = T; p.H = H; p.nseq = nseq;
     dim3 grid(cgn_cdiv(H, 16) * cgn_cdiv(B, 16) * nseq);
@@ -605,7 +634,8 @@ extern "C" int cgn_lstm_seq_bwd_f32(void* stream, const cgn_lstm_bwd_seq* seqs, 
         const cgn_lstm_bwd_seq& s = seqs[i];
         CGN_CHECK_ARG(s.w_hh_t && s.cbuf && s.gates && s.dgates && s.dc_state);
         CGN_CHECK_ARG(((uintptr_t)s.dgates % 16 == 0) && ((uintptr_t)s.w_hh_t % 16 == 0));
-        p.s[i] = {s.w_hh_t, s.cbuf, s.gates, s.dh_ext, s.dh_seed, s.dgates, s.dc_state, s.dh_bs, s.dh_ts, s.reverse};
+        p.s[i] = {s.w_hh_t, s.w_hh, s.cbuf, s.gates, s.dh_ext, s.dh_seed, s.dgates, s.dc_state, s.dh_bs, s.dh_ts,
+                  s.reverse};
     }
     p.B = B; p.T = T; p.H = H; p.nseq = nseq;
     dim3 grid(cgn_cdiv(H, 16) * cgn_cdiv(B, 16) * nseq);
@@ -640,7 +670,7 @@ extern "C" int cgn_lstm_seq_fwd_persistent_f32(void* stream, const cgn_lstm_fwd_
         const cgn_lstm_fwd_seq& s = seqs[i];
         CGN_CHECK_ARG(s.xg && s.w_hh && s.hbuf && s.cbuf && s.gates);
         CGN_CHECK_ARG(((uintptr_t)s.hbuf % 16 == 0) && ((uintptr_t)s.w_hh % 16 == 0));
-        p.s[i] = {s.xg, s.xg_extra, s.w_hh, s.hbuf, s.cbuf, s.gates, s.reverse};
+        p.s[i] = {s.xg, s.xg_extra, s.w_hh, s.hbuf, s.cbuf, s.gates, s.reverse, s.init_zero};
     }
     p.B = B; p.T = T; p.H = H; p.nseq = nseq; p.step = 0;
     hipStream_t st = (hipStream_t)stream;
@@ -665,9 +695,10 @@ extern "C" int cgn_lstm_seq_bwd_persistent_f32(void* stream, const cgn_lstm_bwd_
     BwdParams p;
     for (int i = 0; i < nseq; ++i) {
         const cgn_lstm_bwd_seq& s = seqs[i];
-        CGN_CHECK_ARG(s.w_hh_t && s.cbuf && s.gates && s.dgates && s.dc_state);
+        CGN_CHECK_ARG((s.w_hh_t || s.w_hh) && s.cbuf && s.gates && s.dgates && s.dc_state);
         CGN_CHECK_ARG(((uintptr_t)s.dgates % 16 == 0) && ((uintptr_t)s.w_hh_t % 16 == 0));
-        p.s[i] = {s.w_hh_t, s.cbuf, s.gates, s.dh_ext, s.dh_seed, s.dgates, s.dc_state, s.dh_bs, s.dh_ts, s.reverse};
+        p.s[i] = {s.w_hh_t, s.w_hh, s.cbuf, s.gates, s.dh_ext, s.dh_seed, s.dgates, s.dc_state, s.dh_bs, s.dh_ts,
+                  s.reverse};
     }
     p.B = B; p.T = T; p.H = H; p.nseq = nseq; p.step = 0;
     hipStream_t st = (hipStream_t)stream;

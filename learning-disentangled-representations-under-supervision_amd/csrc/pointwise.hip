@@ -180,7 +180,13 @@ __global__ __launch_bounds__(PW_NT) void colsum_final_kernel(const float* __rest
     const int c = blockIdx.x * PW_NT + threadIdx.x;
     if (c >= Cn) return;
     float s = 0.f;
-    for (int k = 0; k < nchunk; ++k) s += part[(long)k * Cn + c];
+    for (int k0 = 0; k0 < nchunk; k0 += 8) {  // 8 loads in flight; fixed summation order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(long)min(k0 + u, nchunk - 1) * Cn + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (k0 + u < nchunk) ? v[u] : 0.f;
+    }
     out[c] = (beta != 0.f) ? s + beta * out[c] : s;
 }
 
@@ -192,7 +198,13 @@ __global__ __launch_bounds__(PW_NT) void sum_time_kernel(const float* __restrict
         const int b = (int)(i / Cn), c = (int)(i % Cn);
         const float* p = x + (long)b * T * Cn + c;
         float s = 0.f;
-        for (int t = 0; t < T; ++t) s += p[(long)t * Cn];
+        for (int t0 = 0; t0 < T; t0 += 8) {  // 8 loads in flight; fixed summation order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(long)min(t0 + u, T - 1) * Cn];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (t0 + u < T) ? v[u] : 0.f;
+        }
         out[i] = s;
     }
 }

@@ -171,10 +171,15 @@ class LstmSeq:
         self.cbuf = _new((B, T + 1, H), dev)
         self.gates = _new((B, T, 4 * H), dev)
         self.xg_extra = None
+        self.init_zero = False
         self.init_slot = T if reverse else 0
         self.final_slot = 0 if reverse else T
 
     def set_initial(self, h0=None, c0=None):
+        if h0 is None and c0 is None:
+            self.init_zero = True  # the LSTM entry point zeroes the initial slots itself (no extra launches)
+            return
+        self.init_zero = False
         for buf, init in ((self.hbuf, h0), (self.cbuf, c0)):
             slot = buf[:, self.init_slot, :]
             if init is None:
@@ -201,7 +206,7 @@ class LstmSeq:
 
     def fwd_desc(self, w_hh):
         return dict(xg=self.xg, xg_extra=self.xg_extra, w_hh=w_hh, hbuf=self.hbuf, cbuf=self.cbuf, gates=self.gates,
-                    reverse=self.reverse)
+                    reverse=self.reverse, init_zero=self.init_zero)
 
 
 def lstm_run_fwd(seqs, w_hhs):
@@ -214,11 +219,15 @@ def lstm_run_bwd(seqs, w_hhs, dh_exts, dh_seeds, dc_states):
     s0 = seqs[0]
     dev = s0.xg.device
     descs, outs = [], []
+    persistent = ops.lstm_persistent_bytes(len(seqs), s0.B, s0.T, s0.H, dev) > 0
     for s, w, ext, seed, dc in zip(seqs, w_hhs, dh_exts, dh_seeds, dc_states):
-        wt = _new((s.H, 4 * s.H), dev)
-        ops.transpose(w, wt)
+        if persistent and w.is_contiguous():
+            wt = None  # the persistent kernel loads its W_hh slice once, straight from the untransposed weight
+        else:
+            wt = _new((s.H, 4 * s.H), dev)
+            ops.transpose(w, wt)
         dg = _new((s.B, s.T, 4 * s.H), dev)
-        d = dict(w_hh_t=wt, cbuf=s.cbuf, gates=s.gates, dgates=dg, dc_state=dc, dh_seed=seed, reverse=s.reverse)
+        d = dict(w_hh_t=wt, w_hh=w if wt is None else None, cbuf=s.cbuf, gates=s.gates, dgates=dg, dc_state=dc, dh_seed=seed, reverse=s.reverse)
         if ext is not None:
             d["dh_ext"], d["dh_bs"], d["dh_ts"] = ext
         descs.append(d)

@@ -523,6 +523,7 @@ def lstm_seq_fwd(seqs, B, T, H):
             s["w_hh"].data_ptr()
         arr[i].hbuf, arr[i].cbuf, arr[i].gates = s["hbuf"].data_ptr(), s["cbuf"].data_ptr(), s["gates"].data_ptr()
         arr[i].reverse = 1 if s.get("reverse") else 0
+        arr[i].init_zero = 1 if s.get("init_zero") else 0
     nb = lstm_persistent_bytes(len(seqs), B, T, H, dev)
     if nb:
         ws = _lstm_sync_ws(dev)
@@ -532,11 +533,23 @@ def lstm_seq_fwd(seqs, B, T, H):
 
 
 def lstm_seq_bwd(seqs, B, T, H):
-    """seqs: list of dicts(w_hh_t, cbuf, gates, dgates, dc_state, dh_ext=None (+dh_bs, dh_ts), dh_seed=None, reverse)."""
+    """seqs: list of dicts(w_hh_t | w_hh, cbuf, gates, dgates, dc_state, dh_ext=None (+dh_bs, dh_ts), dh_seed=None,
+    reverse). w_hh (untransposed [4H,H]) is enough when the shape takes the persistent kernel."""
     arr = (_lib.LstmBwdSeq * len(seqs))()
     dev = seqs[0]["dgates"].device
+    nb = lstm_persistent_bytes(len(seqs), B, T, H, dev)
     for i, s in enumerate(seqs):
-        for k, shape in (("w_hh_t", (H, 4 * H)), ("cbuf", (B, T + 1, H)), ("gates", (B, T, 4 * H)),
+        w, wt = s.get("w_hh"), s.get("w_hh_t")
+        _req(wt is not None or (w is not None and nb), "lstm_seq_bwd needs w_hh_t (or w_hh on the persistent path)")
+        if w is not None:
+            _chk_f32(w, "w_hh")
+            _req(w.is_contiguous() and tuple(w.shape) == (4 * H, H), "w_hh must be contiguous [4H,H]")
+        if wt is not None:
+            _chk_f32(wt, "w_hh_t")
+            _req(wt.is_contiguous() and tuple(wt.shape) == (H, 4 * H), "w_hh_t must be contiguous [H,4H]")
+        arr[i].w_hh = w.data_ptr() if w is not None else None
+        arr[i].w_hh_t = wt.data_ptr() if wt is not None else None
+        for k, shape in (("cbuf", (B, T + 1, H)), ("gates", (B, T, 4 * H)),
                          ("dgates", (B, T, 4 * H)), ("dc_state", (B, H))):
             _chk_f32(s[k], k)
             _req(s[k].is_contiguous() and tuple(s[k].shape) == shape, "lstm %s must be contiguous %s" % (k, shape))
@@ -550,12 +563,11 @@ def lstm_seq_bwd(seqs, B, T, H):
         if seed is not None:
             _chk_f32(seed, "dh_seed")
             _req(seed.is_contiguous() and tuple(seed.shape) == (B, H), "dh_seed must be [B,H]")
-        arr[i].w_hh_t, arr[i].cbuf, arr[i].gates = s["w_hh_t"].data_ptr(), s["cbuf"].data_ptr(), s["gates"].data_ptr()
+        arr[i].cbuf, arr[i].gates = s["cbuf"].data_ptr(), s["gates"].data_ptr()
         arr[i].dh_ext = ext.data_ptr() if ext is not None else None
         arr[i].dh_seed = seed.data_ptr() if seed is not None else None
         arr[i].dgates, arr[i].dc_state = s["dgates"].data_ptr(), s["dc_state"].data_ptr()
         arr[i].reverse = 1 if s.get("reverse") else 0
-    nb = lstm_persistent_bytes(len(seqs), B, T, H, dev)
     if nb:
         ws = _lstm_sync_ws(dev)
         _call("cgn_lstm_seq_bwd_persistent_f32", dev, arr, len(seqs), B, T, H, _ptr(ws), ws.numel() * 4)

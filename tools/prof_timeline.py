@@ -1,0 +1,35 @@
+"""Timeline of ONE step out of a rocprofv3 kernel-trace .db: start offset, duration, overlap, name.
+usage: prof_timeline.py <results.db> <step-index> [anchor-kernel-substring]"""
+import re
+import sqlite3
+import sys
+
+db, which = sys.argv[1], int(sys.argv[2])
+anchor = sys.argv[3] if len(sys.argv) > 3 else "softmax_nll_fwd"
+c = sqlite3.connect(db)
+rows = c.execute("select name, start, end, grid_x, workgroup_x from kernels order by start").fetchall()
+marks = [i for i, r in enumerate(rows) if anchor in r[0]]
+# a step = from the first kernel after the previous step's last Adam to this step's last kernel; approximate by the
+# midpoint between consecutive anchors' positions in the launch order
+lo = (marks[which - 1] + marks[which]) // 2 if which > 0 else 0
+hi = (marks[which] + marks[which + 1]) // 2
+# refine: cut at the largest idle gap near lo / hi
+def cut(i):
+    best, bi = -1, i
+    for j in range(max(1, i - 60), min(len(rows) - 1, i + 60)):
+        gap = rows[j][1] - max(r[2] for r in rows[max(0, j - 8):j])
+        if gap > best:
+            best, bi = gap, j
+    return bi
+lo, hi = cut(lo), cut(hi)
+seg = rows[lo:hi]
+t0 = seg[0][1]
+end_max = 0
+busy = 0
+print("step %d: %d kernels, span %.1f us" % (which, len(seg), (max(r[2] for r in seg) - t0) / 1e3))
+for i, (name, s, e, gx, wx) in enumerate(seg):
+    short = re.sub(r"\(anonymous namespace\)::", "", name).split("(")[0].replace("void ", "")[:40]
+    ov = sum(1 for r in seg if r[1] < e and r[2] > s) - 1
+    gap = (s - end_max) / 1e3 if end_max else 0.0
+    print("%8.1f %7.1f us  ov %d  gap %5.1f  g%-5d %s" % ((s - t0) / 1e3, (e - s) / 1e3, ov, max(gap, 0.0), gx // max(wx, 1), short))
+    end_max = max(end_max, e)
