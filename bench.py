@@ -183,6 +183,17 @@ def main():
         raise SystemExit("non-finite loss in the benchmark step")
 
     if rank == 0:
+        # HBM bytes per launch of the roofline kernel: PMC counters cannot be read from inside the run, so the figure
+        # comes from the committed rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py; FETCH_SIZE and
+        # WRITE_SIZE in separate runs, FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes)
+        traffic, traffic_src = None, None
+        tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tp):
+            with open(tp) as f:
+                tj = json.load(f)
+            for k, v in tj["kernels"].items():
+                if k.startswith("gemm_kernel<128, true, true, true, false") and k.endswith("g1727"):
+                    traffic, traffic_src = v["traffic"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, %d launches)" % v["launches"]
         recs = prof["records"]
         flops = sum(2.0 * M * N * K for _, _, M, N, K, _, _ in recs)
         ms = sum(e0.elapsed_time(e1) for *_, e0, e1 in recs)
@@ -200,7 +211,8 @@ def main():
                        "launch": ("hipGraph replay" if world == 1 and not args.force_dp else
                                   "hipGraph segments + eager RCCL all-reduce") if use_graph else "eager"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
                          "kernel": "gemm_kernel<128,true,true,true,false,2,16> (NT fp32 MFMA GEMM, 128x128 tile: the "
                                    "vocabulary projection and the fused dlogits GEMM)",
                          "launches_per_step": 2.0,

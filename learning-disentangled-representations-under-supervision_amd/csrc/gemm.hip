@@ -66,6 +66,7 @@ struct GemmParams {
     int a_vec, b_vec;
     int a_transform, epilogue;
     int tiles_m, tiles_n;
+    int order;  // 0: remap over (split, tile), shorter tile axis fastest; 1: same remap, m fastest; 2: remap over tiles only
     float alpha, beta, a_scale, ep_inv_tau, ep_ce_scale;
 };
 
@@ -242,14 +243,33 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
     constexpr int TILE = BT * LDK;  // floats per operand image
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE];
 
+    // Work item = (K split, tile). Default (order 2): the XCD remap runs over the tile list, m fastest (neighbouring
+    // tiles share the B, usually the weight, panel). Orders 0/1 remap over the whole (split, tile) list so that an XCD
+    // owns whole K ranges of a split-K product: that cuts the memory-side fetch of the three tall-K products (PMC:
+    // their 107 MB logits-sized operand is fetched ~4x, profiles/r01_pmc_traffic.txt) but measured no faster to 15 %
+    // slower (tools/gemm_bench.py, GEMM_ORDER=0,1,2): these kernels are not fetch-bound, the Infinity Cache absorbs
+    // the re-reads. Kept as an experiment knob (cgn_debug_set_stages bits 4..7).
     const int ntiles = p.tiles_m * p.tiles_n;
-    const int t = xcd_remap(blockIdx.x, ntiles);
-    // m fastest: neighbouring tiles share the B (usually the weight) panel
-    const int tile_m = t % p.tiles_m;
-    const int tile_n = t / p.tiles_m;
+    int split, t;
+    if (p.order == 2) {
+        split = blockIdx.y;
+        t = xcd_remap(blockIdx.x, ntiles);
+    } else {
+        const int w = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, ntiles * p.splitk);
+        split = w / ntiles;
+        t = w - split * ntiles;
+    }
+    int tile_m, tile_n;
+    if (p.order == 0 && p.tiles_n < p.tiles_m) {
+        tile_n = t % p.tiles_n;
+        tile_m = t / p.tiles_n;
+    } else {
+        tile_m = t % p.tiles_m;
+        tile_n = t / p.tiles_m;
+    }
     const int m0 = tile_m * BT, n0 = tile_n * BT;
 
-    const int kbeg = blockIdx.y * p.k_per_split;
+    const int kbeg = split * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
 
     const int lane = threadIdx.x & 63;
@@ -368,7 +388,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
                 const int row = m0 + wm * (BT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
                 if (row >= p.M) continue;
                 if (p.splitk > 1) {
-                    p.ws[((long)blockIdx.y * p.M + row) * p.N + col] = acc[0][i][j][r];
+                    p.ws[((long)split * p.M + row) * p.N + col] = acc[0][i][j][r];
                 } else {
                     p.C[(long)row * p.ldc + col] = apply_epilogue(p, row, col, acc[0][i][j][r]);
                 }
@@ -430,6 +450,7 @@ bool axis_vec_ok(const cgn_axis& contig, const cgn_axis& other, int n) {
 }
 
 int g_stages = 0;  // 0 = default; tools/gemm_bench.py overrides it through cgn_debug_set_stages
+int g_order = 2;   // tile-order experiment knob (cgn_debug_set_stages bits 4..7); 2 = default
 
 template <int BT, int S, bool VEC, bool EXP>
 void launch_v(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
@@ -522,7 +543,11 @@ int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out
 
 extern "C" int cgn_abi_version(void) { return 2; }
 
-extern "C" void cgn_debug_set_stages(int v) { g_stages = v; }
+extern "C" void cgn_debug_set_stages(int v) {
+    g_stages = v & 15;
+    g_order = (v >> 4) & 15;
+    if (v == 0) g_order = 2;
+}
 
 extern "C" int cgn_gemm_plan(const cgn_gemm_desc* d, int32_t* tile, int32_t* splitk, int32_t* a_kcontig,
                              int32_t* b_kcontig) {
@@ -582,6 +607,7 @@ extern "C" int cgn_gemm_f32(void* stream, const cgn_gemm_desc* d) {
     const long tiles = (long)p.tiles_m * p.tiles_n;
     p.k_per_split = kps;
     p.splitk = splitk;
+    p.order = g_order;
     p.ws = d->workspace;
     p.dyn = d->dyn_scalars;
 
