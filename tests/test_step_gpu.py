@@ -30,6 +30,15 @@ CFGS = {
     # reference-like proportions at reduced size (default TDNN kernels, E=300)
     "mid": dict(max_word_len=12, max_seq_len=10, word_vocab_size=1200, char_vocab_size=64, encoder_rnn_size=64,
                 latent_variable_size=32, decoder_rnn_size=96, sentiment_kernel_num=20),
+    # BASELINE.json configs[0] at FULL size: vocab 10k, seq len 15, batch 32, emb 300, hidden 256, z 32, c dim 1
+    # (reference TDNN kernels, Ks = 3,4,5 x 100 maps); the fp64 oracle step takes a few seconds on the host
+    "cfg1": dict(max_word_len=12, max_seq_len=16, word_vocab_size=10000, char_vocab_size=64, word_embed_size=300,
+                 encoder_rnn_size=256, latent_variable_size=32, decoder_rnn_size=256, decoder_num_layers=2,
+                 sentiment_kernel_size=(3, 4, 5), sentiment_kernel_num=100),
+    # BASELINE.json configs[1] at FULL size (the benchmark workload): vocab 20k, seq len 20, batch 64, hidden 512, z 64
+    "cfg2": dict(max_word_len=12, max_seq_len=21, word_vocab_size=20000, char_vocab_size=64, word_embed_size=300,
+                 encoder_rnn_size=512, latent_variable_size=64, decoder_rnn_size=512, decoder_num_layers=2,
+                 sentiment_kernel_size=(3, 4, 5), sentiment_kernel_num=100),
 }
 
 
@@ -123,7 +132,7 @@ def build(name, dev, seed=0):
 
 
 @pytest.mark.parametrize("name,B,calc_z", [("tiny", 4, False), ("tiny", 5, True), ("odd", 7, True), ("mid", 16, False),
-                                           ("mid", 8, True)])
+                                           ("mid", 8, True), ("cfg1", 32, False), ("cfg2", 64, False)])
 def test_wake_sleep_step_matches_oracle(dev, name, B, calc_z):
     ocfg, oracle, cfg, model = build(name, dev)
     L = ocfg.max_seq_len - 1
@@ -131,7 +140,7 @@ def test_wake_sleep_step_matches_oracle(dev, name, B, calc_z):
     opts = O.make_optimizers(oracle)
     handler = None
     disc_train = enc_gen_train = None
-    for step in range(3):  # three steps: Adam moments and the changed weights are exercised too
+    for step in range(1 if name.startswith("cfg") else 3):  # three steps: Adam moments and the changed weights are exercised too
         data = O.synthetic_batch(ocfg, B, L, seed=100 + step)
         g = torch.Generator().manual_seed(7 + step)
         masks = dict(labelled=(torch.rand(B, F_, generator=g) < 0.7).double() / 0.7,
