@@ -163,6 +163,20 @@ int cgn_lstm_seq_bwd_persistent_f32(void* stream, const cgn_lstm_bwd_seq* seqs /
                                     int32_t T, int32_t H, void* sync_ws, int64_t sync_ws_bytes);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * One beam-search step for S sentences x K beams (rows r = s*K + k), replacing Beam.advance
+ * (utils/beam_search.py:68-99) and the per-sentence state reordering of model/cgn.py:813-838 in the sleep-phase
+ * sampler (sample_from_generator, cgn.py:747-921). Candidates (logits[r,v] - lse[r]) + scores[r]; first != 0: beam 0
+ * only (beam_search.py:79). Per live sentence: scores[r] <- the K best, descending (ties: smaller flat index);
+ * tokens[r] / origin[r] <- word and back-pointer (:88-92); src_rows[r] <- 2*(s*K + origin) + 1 (row of the parent's
+ * new state in a [R, 2, H] history buffer viewed as [2R, H]); hist_tok/hist_org receive the same (this step's slice
+ * of the [steps, R] history); length[s] += 1; done[s] <- 1 when the top beam emits eos (:96-97). Sentences with
+ * done[s] != 0 are frozen: scores kept, tokens = pad, origin = identity. K <= 64, K*V < 2^31.
+ * ---------------------------------------------------------------------------------------------------------- */
+int cgn_beam_topk_f32(void* stream, const float* logits, int64_t ld, const float* lse, int32_t S, int32_t K, int32_t V,
+                      int32_t first, int32_t eos, int32_t pad, float* scores, int32_t* done, int32_t* length,
+                      int64_t* tokens, int32_t* origin, int64_t* src_rows, int64_t* hist_tok, int32_t* hist_org);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Convolution + max-over-time pooling helpers, shared by the text-CNN discriminator
  * (model/discriminator_sentiment.py:56-78; act = 0 ReLU, weight layout 0 = [Co][K][E]) and the char-TDNN
  * (selfModules/tdnn.py:40-43; act = 1 tanh, weight layout 1 = [od][Cc][kW]). The convolution product itself is

@@ -627,3 +627,21 @@ def mul2d(a, b, out):
         _req(t.is_contiguous() and t.numel() == a.numel(), n + " must be contiguous, same size")
     _call("cgn_mul_f32", out.device, _ptr(a), _ptr(b), _ptr(out), a.numel())
     return out
+
+
+def beam_topk(logits, lse, S, K, first, eos, pad, scores, done, length, tokens, origin, src_rows, hist_tok, hist_org):
+    """One beam-search step (cgn_beam_topk_f32): see include/cgn_hip.h. All state tensors live on the device."""
+    _chk_f32(logits, "logits"), _chk_f32(lse, "lse"), _chk_f32(scores, "scores")
+    R = S * K
+    _req(logits.dim() == 2 and logits.shape[0] == R and logits.stride(1) == 1, "logits must be [S*K, V]")
+    V = logits.shape[1]
+    _req(lse.is_contiguous() and lse.numel() == R and scores.is_contiguous() and scores.numel() == R, "lse/scores size")
+    for t_, n, dt, ne in ((done, "done", torch.int32, S), (length, "length", torch.int32, S),
+                          (tokens, "tokens", torch.int64, R), (origin, "origin", torch.int32, R),
+                          (src_rows, "src_rows", torch.int64, R), (hist_tok, "hist_tok", torch.int64, R),
+                          (hist_org, "hist_org", torch.int32, R)):
+        _req(t_.is_cuda and t_.dtype == dt and t_.is_contiguous() and t_.numel() == ne, "%s must be %s[%d]" % (n, dt, ne))
+    _req(1 <= K <= 64 and 0 <= eos < V and 0 <= pad < V, "beam_topk arguments")
+    _call("cgn_beam_topk_f32", logits.device, _ptr(logits), logits.stride(0), _ptr(lse), S, K, V, 1 if first else 0,
+          int(eos), int(pad), _ptr(scores), _ptr(done), _ptr(length), _ptr(tokens), _ptr(origin), _ptr(src_rows),
+          _ptr(hist_tok), _ptr(hist_org))

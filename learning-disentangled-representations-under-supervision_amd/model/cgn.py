@@ -4,8 +4,8 @@ Same class name, constructor, sub-module names (hence state_dict keys) and step-
 model/cgn.py:24-1250. The step closures run the fused HIP step (hip/step.py); the module-level forward helpers
 (encode_for_z, train_rvae, discriminator_forward) run the same kernels through the modules' autograd Functions.
 
-Out of scope this round: the sleep-phase beam sampler (sample_from_generator,
-sample_generator_for_learning, cgn.py:747-1034).
+The sleep-phase beam sampler (sample_from_generator, sample_generator_for_learning, sample; cgn.py:747-1034) runs
+batched on the device (hip/sampler.py).
 """
 import numpy as np
 import torch as t
@@ -331,12 +331,59 @@ class Controlled_Generation_Sentence(nn.Module):
         return valid
 
     # ------------------------------------------------------------------------------------------------------------
-    def sample_from_generator(self, *args, **kwargs):
-        raise NotImplementedError("sleep-phase beam sampler (cgn.py:747-921) is the next row after the training step "
-                                  "(SURVEY.md §8f rank 1); not built in this round")
+    # ------------------------------------------------------------------------------------------------------------
+    # sleep-phase sampler (cgn.py:747-1034): batched beam search on the device (hip/sampler.py)
+    # ------------------------------------------------------------------------------------------------------------
+    def sample_from_generator(self, batch_loader, seq_len, seed, use_cuda, beam_size=10, n_best=1, samples=5,
+                              learning=False):
+        """cgn.py:747-921. Returns (all_sent_codes, allScores): all_sent_codes[b] = list over time of n_best-tuples of
+        word ids (the zip(*hyps) of :879), allScores[b] = the n_best best joint log-probabilities."""
+        if learning:
+            raise NotImplementedError("learning=True (per-token soft distributions, beam_search.py:140-152) is not "
+                                      "used by the training loop (train_functions.py:56 passes learning=False)")
+        if not use_cuda:
+            raise RuntimeError("the sampler runs on the MI355X only (use_cuda must be True)")
+        self.generator.eval()
+        eng = self.step_engine()
+        from ..hip.sampler import BeamSampler
+        w2i = batch_loader.word_to_idx
+        go, eos, pad = w2i[batch_loader.go_token], w2i[batch_loader.end_token], w2i[batch_loader.pad_token]
+        seed = seed[:samples].to(eng.dev, t.float32).contiguous()
+        hyps, scores = BeamSampler(eng).sample(seed, seq_len, beam_size, go, eos, pad, n_best=n_best)
+        all_sent_codes = [list(zip(*h)) for h in hyps]
+        allScores = [sc[:n_best] for sc in scores]
+        return all_sent_codes, allScores
 
-    def sample_generator_for_learning(self, *args, **kwargs):
-        raise NotImplementedError("sleep-phase sampler (cgn.py:993-1034): SURVEY.md §8f rank 1; not built this round")
+    def sample_generator_for_learning(self, data_handler, config, use_cuda=True, sample=10, seed_z=None, seed_c=None):
+        """cgn.py:993-1034: `sample` sentences from z ~ N(0,I), c ~ Bernoulli(0.5). Returns (list of word-id lists,
+        seed_c [sample,1]). seed_z / seed_c optionally pin the random draws."""
+        self.generator.eval()
+        if seed_z is None:
+            seed_z = t.randn([sample, config.latent_variable_size])
+        if seed_c is None:
+            seed_c = t.bernoulli(t.ones(sample, 1) * 0.5)
+        seed = t.cat((seed_z, seed_c), 1)
+        generated_samples, _ = self.sample_from_generator(data_handler.gen_batch_loader, config.max_seq_len, seed,
+                                                          use_cuda, n_best=1, samples=sample, learning=False)
+        all_gen_samples = [[word_n[0] for word_n in batch] for batch in generated_samples]
+        return all_gen_samples, seed_c
+
+    def sample(self, data_handler, config, use_cuda=True, print_sentences=False, samp=5, seed_z=None):
+        """cgn.py:923-991: `samp` latent draws, each decoded with c = 1 and c = 0. Returns (sentences, seed_c)."""
+        if seed_z is None:
+            seed_z = t.randn([samp, config.latent_variable_size])
+        seed_z = seed_z.unsqueeze(1).repeat(1, 2, 1).view(-1, config.latent_variable_size)
+        seed_c = t.ones(2 * samp, 1)
+        seed_c[1::2] = 0
+        seed = t.cat((seed_z, seed_c), 1)
+        sentences, _ = self.sample_from_generator(data_handler.gen_batch_loader, config.max_seq_len, seed, use_cuda,
+                                                  n_best=1, samples=2 * samp)
+        all_sentences = [[word_n[0] for word_n in batch] for batch in sentences]
+        if print_sentences:
+            loader = data_handler.gen_batch_loader
+            for c, sen in zip(seed_c.view(-1).tolist(), all_sentences):
+                print('c={%d} : %s' % (c, ' '.join(loader.decode_word(w) for w in sen)))
+        return all_sentences, seed_c
 
 
 def _gen_mask(generator, dec_word, dropout, E, dev):

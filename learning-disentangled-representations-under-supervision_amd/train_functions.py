@@ -1,10 +1,10 @@
 """Alternating wake-sleep training loop. Same function names/arguments as the reference's train_functions.py:7-108;
 logging/validation/TensorBoard glue (train_functions.py:111-559) is host-side and out of scope.
 
-One wake-sleep step (train_functions.py:49-108) = generated samples -> discriminator step -> c inference ->
-encoder/generator step. The sleep-phase beam sampler is not built yet: when the model has no
-sampler, `data_handler.synthetic_generated_samples(n)` supplies the "generated" token batch, which is also what the
-benchmark does.
+One wake-sleep step (train_functions.py:49-108) = generated samples (batched beam sampler, hip/sampler.py) ->
+discriminator step -> c inference -> encoder/generator step. A model without a sampler (NotImplementedError) falls
+back to `data_handler.synthetic_generated_samples(n)`; the benchmark times the step without the sampler on a synthetic
+"generated" batch.
 """
 import os
 

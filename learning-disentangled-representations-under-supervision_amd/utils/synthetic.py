@@ -14,6 +14,14 @@ def word_embeddings(config, seed=1234):
 class _GenBatchLoader:
     def __init__(self, config, L, train_lines, seed):
         self.config, self.L, self.train_lines, self.seed = config, L, train_lines, seed
+        # special tokens are the last three vocabulary indices (batch_loader.py:81-85, :170)
+        V = config.word_vocab_size
+        self.pad_token, self.go_token, self.end_token = '_', '>', '|'
+        self.word_to_idx = {self.pad_token: V - 3, self.go_token: V - 2, self.end_token: V - 1}
+
+    def decode_word(self, idx):
+        inv = {v: k for k, v in self.word_to_idx.items()}
+        return inv.get(int(idx), 'w%d' % int(idx))
 
     def next_batch(self, batch_size, target_str, start_index):
         """Five arrays like batch_loader.py:271-316: [enc_word, enc_char, dec_word, dec_char, target] (int64)."""

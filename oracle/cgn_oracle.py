@@ -464,3 +464,52 @@ def make_optimizers(model):
     enc = torch.optim.Adam(model.encoder_params(), lr)
     gen = torch.optim.Adam(model.generator_params(), lr)
     return disc, enc, gen
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Sleep-phase beam sampler: model/cgn.py:747-921 (sample_from_generator), utils/beam_search.py:16-153 (Beam),
+# model/generator.py:24-43 (only_decoder_beam). Restated per sentence: in the reference the sentences advance in
+# lock-step but never interact, so one sentence = one Beam + its own [layers, beam, H] LSTM state.
+# Conscious deviation: the reference tiles the seed `zc` over ALL sentences even after finished ones
+# were compacted away (generator.py:30-32 vs cgn.py:845-869), which pairs the remaining sentences with the wrong
+# seeds; here every sentence keeps its own seed. Until the first sentence finishes the two are identical.
+# Python-2 integer divisions (beam_search.py:88 `bestScoresId / num_words`) are written as floor divisions.
+# --------------------------------------------------------------------------------------------------------------
+def sample_from_generator(model, seed, seq_len, beam_size, go, eos, pad, n_best=1):
+    """seed [S, Z+C]. Returns (hyps, scores): hyps[s] = list over n_best of token lists (the walk-back of
+    Beam.get_hyp, beam_search.py:121-132), scores[s] = the beam's final scores sorted descending (sort_best :101)."""
+    gen, emb = model.generator, model.embedding.word_embed
+    V = gen.fc.out_features
+    hyps, all_scores = [], []
+    with torch.no_grad():
+        for s in range(seed.shape[0]):
+            zc = seed[s:s + 1]
+            scores = torch.zeros(beam_size, dtype=seed.dtype)  # beam_search.py:31
+            prev_ks, next_ys = [], [torch.full((beam_size,), pad, dtype=torch.int64)]  # :34-37
+            next_ys[0][0] = go  # :38
+            state = None
+            for _ in range(seq_len):  # cgn.py:786
+                x = emb(next_ys[-1]).unsqueeze(1)  # cgn.py:793  [K,1,E]
+                x = torch.cat([x, zc.expand(beam_size, -1).unsqueeze(1)], 2)  # generator.py:30-39
+                out, state = gen.rnn(x, state)  # generator.py:41
+                word_lk = F.log_softmax(gen.fc(out.squeeze(1)), dim=1)  # cgn.py:800-803  [K,V]
+                beam_lk = word_lk + scores.unsqueeze(1) if prev_ks else word_lk[0]  # beam_search.py:76-79
+                best, best_id = beam_lk.reshape(-1).topk(beam_size, 0, True, True)  # :83
+                scores = best
+                prev_k = best_id // V  # :88
+                prev_ks.append(prev_k)
+                next_ys.append(best_id - prev_k * V)  # :92
+                state = tuple(st.index_select(1, prev_k) for st in state)  # cgn.py:823-838
+                if next_ys[-1][0].item() == eos:  # beam_search.py:96-97
+                    break
+            sc, ks = torch.sort(scores, 0, True)  # :101-103
+            out_h = []
+            for k in ks[:n_best].tolist():
+                hyp = []
+                for j in range(len(prev_ks) - 1, -1, -1):  # :127-129
+                    hyp.append(int(next_ys[j + 1][k]))
+                    k = int(prev_ks[j][k])
+                out_h.append(hyp[::-1])
+            hyps.append(out_h)
+            all_scores.append(sc)
+    return hyps, all_scores

@@ -1,0 +1,68 @@
+"""GPU: the batched on-device beam sampler (hip/sampler.py, cgn_beam_topk_f32) against the oracle's restatement of
+sample_from_generator / Beam (model/cgn.py:747-921, utils/beam_search.py) in fp64 on identical weights and seeds:
+identical token sequences, joint log-probabilities within 1e-4."""
+import pytest
+import torch
+
+from oracle import cgn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(max_word_len=12, max_seq_len=12, word_vocab_size=1200, char_vocab_size=64, encoder_rnn_size=64,
+           latent_variable_size=32, decoder_rnn_size=96, sentiment_kernel_num=20)
+
+
+def _build(dev, eos_bias=0.0, seed=5, scale=3.0):
+    import ldrs_amd  # noqa: F401
+    from ldrs_amd.model.cgn import Controlled_Generation_Sentence
+    from ldrs_amd.utils.config import Config
+    from ldrs_amd.utils.synthetic import SyntheticDataHandler
+    kw = dict(CFG)
+    pos = [kw.pop(k) for k in ("max_word_len", "max_seq_len", "word_vocab_size", "char_vocab_size")]
+    cfg = Config(*pos, 5e-5, 7.9, 0.1, 0.1, 1.0, **kw)
+    ocfg = O.OracleConfig(**CFG)
+    torch.manual_seed(seed)
+    emb = O.synthetic_word_embed(ocfg)
+    oracle = O.CGN(ocfg, emb).double()
+    with torch.no_grad():
+        oracle.generator.fc.weight.mul_(scale)  # a peaked vocabulary distribution: well separated candidates
+        oracle.generator.fc.bias[ocfg.word_vocab_size - 1] += eos_bias
+    model = Controlled_Generation_Sentence(cfg, emb)
+    model.load_state_dict({k: v.float() for k, v in oracle.state_dict().items()})
+    model = model.to(dev)
+    return cfg, ocfg, oracle, model, SyntheticDataHandler(cfg, 8, 10)
+
+
+@pytest.mark.parametrize("S,K,eos_bias", [(6, 5, 0.0), (10, 10, 2.5), (3, 1, 0.0), (7, 4, 4.0)])
+def test_beam_sampler_matches_oracle(dev, S, K, eos_bias):
+    cfg, ocfg, oracle, model, handler = _build(dev, eos_bias)
+    V = ocfg.word_vocab_size
+    pad, go, eos = V - 3, V - 2, V - 1
+    g = torch.Generator().manual_seed(100 + S)
+    seed = torch.cat([torch.randn(S, ocfg.latent_variable_size, generator=g),
+                      torch.bernoulli(torch.full((S, 1), 0.5), generator=g)], 1)
+    ref_h, ref_s = O.sample_from_generator(oracle, seed.double(), ocfg.max_seq_len, K, go, eos, pad, n_best=min(2, K))
+    codes, scores = model.sample_from_generator(handler.gen_batch_loader, cfg.max_seq_len, seed, True, beam_size=K,
+                                                n_best=min(2, K), samples=S)
+    assert len(codes) == S
+    finished = 0
+    for s in range(S):
+        got = [list(h) for h in zip(*codes[s])]  # back from the zip(*hyps) layout of cgn.py:879
+        assert got == ref_h[s], (s, got, ref_h[s])
+        finished += ref_h[s][0][-1] == eos
+        for a, b in zip(scores[s].tolist(), ref_s[s].tolist()):
+            assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (s, a, b)
+    if eos_bias >= 2.5:
+        assert 0 < finished, "no sentence finished early: the frozen-beam path was not exercised"
+
+
+def test_sample_generator_for_learning_api(dev):
+    """cgn.py:993-1034 / train_functions.py:7-17: lists of word ids + the codes c, usable as a discriminator batch."""
+    import ldrs_amd  # noqa: F401
+    from ldrs_amd import train_functions
+    cfg, ocfg, oracle, model, handler = _build(dev)
+    sents, c = train_functions.generate_samples_for_disc_training(model, handler, cfg, True, 8, 4)
+    assert len(sents) == 8 and tuple(c.shape) == (8, 1)
+    assert all(1 <= len(s) <= cfg.max_seq_len and all(0 <= w < ocfg.word_vocab_size for w in s) for s in sents)
+    batch = handler.create_sentiment_batch(sents)
+    assert batch.shape[0] == 8
