@@ -66,3 +66,19 @@ def test_sample_generator_for_learning_api(dev):
     assert all(1 <= len(s) <= cfg.max_seq_len and all(0 <= w < ocfg.word_vocab_size for w in s) for s in sents)
     batch = handler.create_sentiment_batch(sents)
     assert batch.shape[0] == 8
+
+
+def test_train_complete_model_runs_the_whole_wake_sleep_loop(dev):
+    """train_functions.py:19-108 end to end: sampler -> discriminator step -> c inference -> encoder/generator step."""
+    import ldrs_amd  # noqa: F401
+    from ldrs_amd import train_functions
+    from ldrs_amd.utils.synthetic import SyntheticDataHandler
+    cfg, ocfg, oracle, model, _ = _build(dev)
+    handler = SyntheticDataHandler(cfg, 20, cfg.max_seq_len - 1, num_batches=3)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    d, eg = train_functions.train_complete_model(model, handler, cfg, True, 0.3, None, None, "t", num_steps=3)
+    vals = [float(x) for x in d] + [float(x) for x in eg]
+    assert all(v == v and abs(v) < 1e6 for v in vals), vals
+    moved = [n for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n])]
+    assert any(n.startswith("generator.") for n in moved) and any(n.startswith("sentiment_discriminator.") for n in moved)
+    assert "embedding.word_embed.weight" not in moved
