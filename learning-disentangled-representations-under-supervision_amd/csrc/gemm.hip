@@ -508,6 +508,27 @@ int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out
             bt = 64;
     }
     const long tiles = bt == 128 ? t128 : t64;
+    if (splitk <= 0 && bt == 128 && d->K >= 4096) {  // tall-K only: a split of the K = 1344 dW_fc product (sk 2) won 11 %
+        // alone but lost it again inside the step (123 MB of slab traffic beside the LSTM backward on the main stream)
+        // 128-tile: a CU works its blocks off at a constant rate whether 1 or 2 are resident, so the time is
+        // ceil(blocks / 256 CUs) block-times of K/splitk steps each. Pick the split count that minimises that product
+        // (plus ~2 K steps of fill/drain per block and the slab traffic of each extra split). Measured on the three
+        // logits-sized tall-K products of the CGN step (tools/gemm_bench.py sweeps): 44 tiles: sk 11 -> 335 us, 12 ->
+        // 406, 16 -> 341, 23 -> 325; 33 tiles: sk 15 -> 250, 16 -> 290; 628 tiles, K = 1344: sk 1 -> 394, 2 -> 352.
+        const int max_sk = (int)(d->K / 512 > 64 ? 64 : d->K / 512);
+        long best_cost = -1;
+        int best = 1;
+        for (int sk = 1; sk <= (max_sk < 1 ? 1 : max_sk); ++sk) {
+            const long kps = (long)cgn_cdiv(cgn_cdiv(d->K, sk), KROUND) * KROUND;
+            const long per_cu = (tiles * sk + 255) / 256;
+            const long cost = per_cu * (kps + 64) + (sk > 1 ? 8L * sk : 0);
+            if (best_cost < 0 || cost < best_cost) {
+                best_cost = cost;
+                best = sk;
+            }
+        }
+        splitk = best;
+    }
     if (splitk <= 0) {
         // Measured (tools/gemm_bench.py sweeps): with >= 2 blocks per CU a split only adds slab traffic; below that,
         // splitting K until ~1024 blocks exist wins as long as every split keeps a few K steps. Products with a
