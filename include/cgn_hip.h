@@ -88,6 +88,12 @@ typedef struct cgn_gemm_desc {
 } cgn_gemm_desc;
 
 int cgn_gemm_f32(void* stream, const cgn_gemm_desc* desc /* host */);
+/* n <= 8 independent products in ONE launch (64x64 tiles, no split-K, linear epilogue, no A transform; all members
+ * must have the same operand orientations). For the chains of small same-shaped convolution products: the six
+ * char-TDNN widths (selfModules/tdnn.py:41-44, a Python loop over F.conv1d) and the text-CNN's filter widths
+ * (model/discriminator_sentiment.py:64, a list comprehension over nn.Conv2d). Same results as n cgn_gemm_f32 calls
+ * forced to tile 64 / split 1. */
+int cgn_gemm_group_f32(void* stream, const cgn_gemm_desc* descs /* host array */, int32_t n);
 /* Which kernel variant cgn_gemm_f32 would launch for `desc` (square tile 64|128, split-K factor, operand
  * orientations); used by bench.py to attribute per-launch timings to kernel symbols. Launches nothing. */
 int cgn_gemm_plan(const cgn_gemm_desc* desc /* host */, int32_t* tile, int32_t* splitk, int32_t* a_kcontig,
@@ -200,6 +206,11 @@ typedef struct cgn_conv_widths {
  * (-1 where the ReLU gate is closed). */
 int cgn_act_maxpool_f32(void* stream, const float* conv, int32_t B, int32_t P, int32_t Co, int32_t act, float* feat,
                         int64_t ldf, int32_t col0, int32_t* arg, int64_t lda);
+/* The same for n <= 8 widths in one launch: width i has its own conv buffer conv[i] [B*P[i], Co[i]] and writes columns
+ * col0[i] .. col0[i]+Co[i] of feat / arg (the torch.cat over widths of tdnn.py:46, discriminator_sentiment.py:70). */
+int cgn_act_maxpool_group_f32(void* stream, int32_t n, const float* const* conv /* host array of device pointers */,
+                              const int32_t* P /* host */, const int32_t* Co /* host */, const int32_t* col0 /* host */,
+                              int32_t B, int32_t act, float* feat, int64_t ldf, int32_t* arg, int64_t lda);
 /* dX[b, 0:L, 0:E] (sentence stride sent_stride) from dfeat [B,F] through the kept windows; feat needed for tanh. */
 int cgn_conv_bwd_dx_f32(void* stream, const cgn_conv_widths* widths /* host */, const float* dfeat, const float* feat,
                         const int32_t* arg, int32_t B, int32_t L, int32_t E, float* dx, int64_t sent_stride);

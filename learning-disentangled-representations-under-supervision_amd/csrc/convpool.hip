@@ -46,6 +46,49 @@ __global__ __launch_bounds__(256) void act_maxpool_kernel(const float* __restric
     }
 }
 
+// The same for up to 8 widths in ONE launch (each width has its own conv buffer, position count and column range).
+struct PoolGroup {
+    const float* conv[8];
+    int P[8], Co[8], col0[8], end[8];  // end: running sum of Co
+    int n;
+};
+__global__ __launch_bounds__(256) void act_maxpool_group_kernel(const PoolGroup g, int B, int act,
+                                                                float* __restrict__ feat, long ldf,
+                                                                int32_t* __restrict__ arg, long lda) {
+    const int F = g.end[g.n - 1];
+    const long total = (long)B * F;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / F), f = (int)(i % F);
+        int j = 0;
+        while (j + 1 < g.n && f >= g.end[j]) ++j;
+        const int co = f - (j ? g.end[j - 1] : 0);
+        const int P = g.P[j], Co = g.Co[j];
+        const float* p = g.conv[j] + (long)b * P * Co + co;
+        float best = p[0];
+        int bi = 0;
+        for (int t0 = 1; t0 < P; t0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(long)min(t0 + u, P - 1) * Co];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (t0 + u < P && v[u] > best) {
+                    best = v[u];
+                    bi = t0 + u;
+                }
+            }
+        }
+        const int col = g.col0[j] + co;
+        if (act == ACT_TANH) {
+            feat[(long)b * ldf + col] = tanhf(best);
+            arg[(long)b * lda + col] = bi;
+        } else {
+            feat[(long)b * ldf + col] = fmaxf(best, 0.f);
+            arg[(long)b * lda + col] = (best > 0.f) ? bi : -1;
+        }
+    }
+}
+
 constexpr int MAXW = 8;
 struct ConvWidths {
     const float* W[MAXW];
@@ -261,6 +304,29 @@ extern "C" int cgn_act_maxpool_f32(void* stream, const float* conv, int32_t B, i
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(act_maxpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, conv, B, P, Co, act, feat,
                        (long)ldf, col0, arg, (long)lda);
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}
+
+extern "C" int cgn_act_maxpool_group_f32(void* stream, int32_t n, const float* const* conv, const int32_t* P,
+                                         const int32_t* Co, const int32_t* col0, int32_t B, int32_t act, float* feat,
+                                         int64_t ldf, int32_t* arg, int64_t lda) {
+    CGN_CHECK_ARG(n >= 1 && n <= 8 && conv && P && Co && col0 && B >= 0 && (act == ACT_RELU || act == ACT_TANH));
+    if (B == 0) return CGN_OK;
+    CGN_CHECK_ARG(feat && arg);
+    PoolGroup g;
+    int end = 0;
+    for (int i = 0; i < n; ++i) {
+        CGN_CHECK_ARG(conv[i] && P[i] >= 1 && Co[i] >= 1 && col0[i] >= 0 && ldf >= col0[i] + Co[i] && lda >= col0[i] + Co[i]);
+        g.conv[i] = conv[i]; g.P[i] = P[i]; g.Co[i] = Co[i]; g.col0[i] = col0[i];
+        end += Co[i];
+        g.end[i] = end;
+    }
+    g.n = n;
+    int blocks = cgn_cdiv((long)B * end, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(act_maxpool_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, B, act, feat,
+                       (long)ldf, arg, (long)lda);
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }

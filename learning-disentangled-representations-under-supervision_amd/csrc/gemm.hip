@@ -235,30 +235,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // S: register stages = K tiles of global loads in flight per thread. Mid-size products of the CGN step have only
 // ~1 block per CU (260-700 tiles), so a wave must cover the L2/HBM round trip (~1-2 us) by itself: with one tile in
 // flight it stalls every K step (0.43 us of MFMA work per step).
-template <int BT, bool A_KC, bool B_KC, bool VEC, bool EXP, int S, int BK = (BT == 128 ? 16 : 32)>
-__global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
+template <int BT, bool A_KC, bool B_KC, bool VEC, bool EXP, int S, int BK>
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, const int t) {
     constexpr int TW = BT / 64;  // 32x32 accumulators per wave along each dim
     constexpr int LDK = BK + 4;  // LDS row stride (floats) of both operand images
     // One LDS array (both operands, two buffers): keeps every carve offset explicit and 16-byte aligned.
     constexpr int TILE = BT * LDK;  // floats per operand image
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE];
 
-    // Work item = (K split, tile). Default (order 2): the XCD remap runs over the tile list, m fastest (neighbouring
-    // tiles share the B, usually the weight, panel). Orders 0/1 remap over the whole (split, tile) list so that an XCD
-    // owns whole K ranges of a split-K product: that cuts the memory-side fetch of the three tall-K products (PMC:
-    // their 107 MB logits-sized operand is fetched ~4x, profiles/r01_pmc_traffic.txt) but measured no faster to 15 %
-    // slower (tools/gemm_bench.py, GEMM_ORDER=0,1,2): these kernels are not fetch-bound, the Infinity Cache absorbs
-    // the re-reads. Kept as an experiment knob (cgn_debug_set_stages bits 4..7).
-    const int ntiles = p.tiles_m * p.tiles_n;
-    int split, t;
-    if (p.order == 2) {
-        split = blockIdx.y;
-        t = xcd_remap(blockIdx.x, ntiles);
-    } else {
-        const int w = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, ntiles * p.splitk);
-        split = w / ntiles;
-        t = w - split * ntiles;
-    }
     int tile_m, tile_n;
     if (p.order == 0 && p.tiles_n < p.tiles_m) {
         tile_n = t % p.tiles_n;
@@ -395,6 +379,45 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
             }
         }
     }
+}
+
+template <int BT, bool A_KC, bool B_KC, bool VEC, bool EXP, int S, int BK = (BT == 128 ? 16 : 32)>
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
+    // Work item = (K split, tile). Default (order 2): the XCD remap runs over the tile list, m fastest (neighbouring
+    // tiles share the B, usually the weight, panel). Orders 0/1 remap over the whole (split, tile) list so that an XCD
+    // owns whole K ranges of a split-K product: that cuts the memory-side fetch of the three tall-K products (PMC:
+    // their 107 MB logits-sized operand is fetched ~4x, profiles/r01_pmc_traffic.txt) but measured no faster to 15 %
+    // slower (tools/gemm_bench.py, GEMM_ORDER=0,1,2): these kernels are not fetch-bound, the Infinity Cache absorbs
+    // the re-reads. Kept as an experiment knob (cgn_debug_set_stages bits 4..7).
+    const int ntiles = p.tiles_m * p.tiles_n;
+    int split, t;
+    if (p.order == 2) {
+        split = blockIdx.y;
+        t = xcd_remap(blockIdx.x, ntiles);
+    } else {
+        const int w = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, ntiles * p.splitk);
+        split = w / ntiles;
+        t = w - split * ntiles;
+    }
+    gemm_tile<BT, A_KC, B_KC, VEC, EXP, S, BK>(p, split, t);
+}
+
+// Grouped launch: up to GROUP_MAX independent products (same kernel variant, no split-K) in ONE launch; block b works
+// on the product whose tile range contains b. For chains of small same-shaped products (the six char-TDNN widths, the
+// text-CNN's filter widths) the launch boundaries and the drain/fill between them cost more than the arithmetic.
+constexpr int GROUP_MAX = 8;
+struct GemmGroup {
+    GemmParams p[GROUP_MAX];
+    int tile_end[GROUP_MAX];  // running sum of tile counts
+    int n;
+};
+
+template <int BT, bool A_KC, bool B_KC, bool VEC, int S, int BK = (BT == 128 ? 16 : 32)>
+__global__ __launch_bounds__(NT, 2) void gemm_group_kernel(const GemmGroup g) {
+    int j = 0;
+    while (j + 1 < g.n && (int)blockIdx.x >= g.tile_end[j]) ++j;  // block-uniform
+    const int t = blockIdx.x - (j ? g.tile_end[j - 1] : 0);
+    gemm_tile<BT, A_KC, B_KC, VEC, false, S, BK>(g.p[j], 0, t);
 }
 
 // Sums the split-K slabs in fixed order z = 0..splitk-1 (bitwise reproducible). VEC: four consecutive columns per
@@ -583,7 +606,8 @@ extern "C" int cgn_gemm_plan(const cgn_gemm_desc* d, int32_t* tile, int32_t* spl
     return CGN_OK;
 }
 
-extern "C" int cgn_gemm_f32(void* stream, const cgn_gemm_desc* d) {
+// Validates a descriptor and fills the kernel parameters (everything except the tile / split-K plan).
+static int prepare_gemm(const cgn_gemm_desc* d, GemmParams& p, bool& a_kc, bool& b_kc) {
     CGN_CHECK_ARG(d != nullptr);
     CGN_CHECK_ARG(d->M >= 0 && d->N >= 0 && d->K >= 0);
     if (d->M == 0 || d->N == 0) return CGN_OK;
@@ -601,11 +625,10 @@ extern "C" int cgn_gemm_f32(void* stream, const cgn_gemm_desc* d) {
         CGN_CHECK_ARG(d->ep_logits && d->ep_lse && d->ep_rowdot && d->ep_target && d->ep_ld >= d->N);
     CGN_CHECK_ARG(d->force_tile == 0 || d->force_tile == 64 || d->force_tile == 128);
     // an operand is "k-contiguous" when its k stride is 1; otherwise lanes run along its row index
-    const bool a_kc = d->a_k.stride == 1 || d->a_m.stride != 1;
-    const bool b_kc = d->b_k.stride == 1 || d->b_n.stride != 1;
+    a_kc = d->a_k.stride == 1 || d->a_m.stride != 1;
+    b_kc = d->b_k.stride == 1 || d->b_n.stride != 1;
     CGN_CHECK_ARG(d->a_transform == CGN_ATRANS_NONE || a_kc);
 
-    GemmParams p;
     p.A = d->A; p.B = d->B; p.C = d->C;
     p.bias0 = d->bias0; p.bias1 = d->bias1; p.a_row_param = d->a_row_param;
     p.ep_logits = d->ep_logits; p.ep_lse = d->ep_lse; p.ep_rowdot = d->ep_rowdot; p.ep_target = d->ep_target;
@@ -617,7 +640,20 @@ extern "C" int cgn_gemm_f32(void* stream, const cgn_gemm_desc* d) {
     p.ep_inv_tau = d->ep_inv_tau; p.ep_ce_scale = d->ep_ce_scale;
     p.a_vec = ((uintptr_t)d->A % 16 == 0) && a_kc && axis_vec_ok(d->a_k, d->a_m, d->K);
     p.b_vec = ((uintptr_t)d->B % 16 == 0) && b_kc && axis_vec_ok(d->b_k, d->b_n, d->K);
+    p.ws = d->workspace;
+    p.dyn = d->dyn_scalars;
+    p.order = g_order;
+    return CGN_OK;
+}
 
+extern "C" int cgn_gemm_f32(void* stream, const cgn_gemm_desc* d) {
+    GemmParams p;
+    bool a_kc = false, b_kc = false;
+    {
+        const int rc = prepare_gemm(d, p, a_kc, b_kc);
+        if (rc) return rc;
+    }
+    if (d->M == 0 || d->N == 0) return CGN_OK;
     int bt, splitk, kps;
     {
         const int rc = plan_gemm(d, &bt, &splitk, &kps);
@@ -628,9 +664,6 @@ extern "C" int cgn_gemm_f32(void* stream, const cgn_gemm_desc* d) {
     const long tiles = (long)p.tiles_m * p.tiles_n;
     p.k_per_split = kps;
     p.splitk = splitk;
-    p.order = g_order;
-    p.ws = d->workspace;
-    p.dyn = d->dyn_scalars;
 
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)tiles, (unsigned)splitk);
@@ -651,5 +684,62 @@ extern "C" int cgn_gemm_f32(void* stream, const cgn_gemm_desc* d) {
             hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, s, p);
         CGN_LAUNCH_CHECK();
     }
+    return CGN_OK;
+}
+
+template <bool VEC>
+static void launch_group(const GemmGroup& g, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s) {
+    if (a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_group_kernel<64, true, true, VEC, 2>), dim3(blocks), dim3(NT), 0, s, g);
+    else if (a_kc && !b_kc)
+        hipLaunchKernelGGL((gemm_group_kernel<64, true, false, VEC, 2>), dim3(blocks), dim3(NT), 0, s, g);
+    else if (!a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_group_kernel<64, false, true, VEC, 2>), dim3(blocks), dim3(NT), 0, s, g);
+    else
+        hipLaunchKernelGGL((gemm_group_kernel<64, false, false, VEC, 2>), dim3(blocks), dim3(NT), 0, s, g);
+}
+
+extern "C" int cgn_gemm_group_f32(void* stream, const cgn_gemm_desc* descs, int32_t n) {
+    CGN_CHECK_ARG(descs && n >= 1 && n <= GROUP_MAX);
+    GemmGroup g;
+    g.n = 0;
+    bool a_kc0 = false, b_kc0 = false, vec0 = false;
+    long blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const cgn_gemm_desc* d = descs + i;
+        GemmParams p;
+        bool a_kc = false, b_kc = false;
+        const int rc = prepare_gemm(d, p, a_kc, b_kc);
+        if (rc) return rc;
+        CGN_CHECK_ARG(d->a_transform == CGN_ATRANS_NONE && d->epilogue == CGN_EPI_LINEAR);
+        if (d->M == 0 || d->N == 0) continue;
+        const bool vec = (!a_kc || p.a_vec) && (!b_kc || p.b_vec);
+        if (g.n == 0) {
+            a_kc0 = a_kc; b_kc0 = b_kc; vec0 = vec;
+        } else {
+            CGN_CHECK_ARG(a_kc == a_kc0 && b_kc == b_kc0);  // one kernel variant per group
+            vec0 = vec0 && vec;                              // the scalar-load variant serves every member
+        }
+        p.tiles_m = cgn_cdiv(d->M, 64);
+        p.tiles_n = cgn_cdiv(d->N, 64);
+        p.splitk = 1;
+        p.k_per_split = cgn_cdiv(d->K > 0 ? d->K : 1, KROUND) * KROUND;
+        p.order = 2;
+        blocks += (long)p.tiles_m * p.tiles_n;
+        CGN_CHECK_ARG(blocks < (1L << 30));
+        g.p[g.n] = p;
+        g.tile_end[g.n] = (int)blocks;
+        ++g.n;
+    }
+    if (g.n == 0) return CGN_OK;
+    if (!vec0) {
+        for (int i = 0; i < g.n; ++i) g.p[i].a_vec = g.p[i].b_vec = 0;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (vec0)
+        launch_group<true>(g, a_kc0, b_kc0, (unsigned)blocks, s);
+    else
+        launch_group<false>(g, a_kc0, b_kc0, (unsigned)blocks, s);
+    CGN_LAUNCH_CHECK();
     return CGN_OK;
 }

@@ -48,6 +48,7 @@ def tdnn_conv_fwd(xw, N, Wl, kernels):
     feat = _new((N, S), dev)
     arg = _new((N, S), dev, torch.int32)
     col = 0
+    calls, convs, Ps, cols = [], [], [], []
     for k in kernels:
         od, _, kW = k.shape
         if kW > Wl:
@@ -55,11 +56,14 @@ def tdnn_conv_fwd(xw, N, Wl, kernels):
         P = Wl - kW + 1
         conv = _new((N * P, od), dev)
         # row (n,p) = xw[n, p:p+kW, :] (contiguous kW*Cc floats, order (j,c)); weight element (o, c, j) -> k = j*Cc + c
-        ops.gemm(xw, k, conv, M=N * P, N=od, K=kW * Cc,
-                 a_m=Axis(Cc, P, Wl * Cc), a_k=LIN,
-                 b_k=Axis(kW, Cc, 1), b_n=Axis(Cc * kW, 0, 0))
-        ops.act_maxpool(conv, N, P, ACT_TANH, feat, col, arg)
+        calls.append((xw, k, conv, dict(M=N * P, N=od, K=kW * Cc, a_m=Axis(Cc, P, Wl * Cc), a_k=LIN,
+                                        b_k=Axis(kW, Cc, 1), b_n=Axis(Cc * kW, 0, 0))))
+        convs.append(conv), Ps.append(P), cols.append(col)
         col += od
+    # all widths in one grouped GEMM launch + one pooling launch (the reference loops over F.conv1d, tdnn.py:41-44)
+    ops.gemm_group(calls)
+    for i in range(0, len(convs), 8):
+        ops.act_maxpool_group(convs[i:i + 8], N, Ps[i:i + 8], ACT_TANH, feat, cols[i:i + 8], arg)
     return feat, dict(xw=xw, feat=feat, arg=arg, N=N, W=Wl, Cc=Cc)
 
 
@@ -256,7 +260,7 @@ def lstm_param_grads(seq, dgates, x_operand, dW_ih, dW_hh, db_ih, db_hh, beta=0.
 # ------------------------------------------------------------------------------------------------------------------
 # text-CNN discriminator (model/discriminator_sentiment.py:56-78)
 # ------------------------------------------------------------------------------------------------------------------
-def textcnn_features_fwd(x, B, L, E, sent_stride, conv_w, conv_b):
+def textcnn_features_fwd(x, B, L, E, sent_stride, conv_w, conv_b, grouped=True):
     """x: tensor whose element (b,t,e) sits at b*sent_stride + t*E + e. Returns feat [B,F], arg [B,F]."""
     dev = x.device
     Cos = [w.shape[0] for w in conv_w]
@@ -264,13 +268,24 @@ def textcnn_features_fwd(x, B, L, E, sent_stride, conv_w, conv_b):
     feat = _new((B, F), dev)
     arg = _new((B, F), dev, torch.int32)
     col = 0
+    calls, convs, Ps, cols = [], [], [], []
     for w, b in zip(conv_w, conv_b):
         Co, _, K, Ew = w.shape
         if K > L:
             raise RuntimeError("Kernel size can't be greater than actual input size (K=%d, L=%d)" % (K, L))
         P = L - K + 1
         conv = _new((B * P, Co), dev)
-        ops.gemm(x, w.view(Co, K * E).t(), conv, M=B * P, K=K * E, a_m=Axis(E, P, sent_stride), a_k=LIN, bias0=b)
-        ops.act_maxpool(conv, B, P, ACT_RELU, feat, col, arg)
+        calls.append((x, w.view(Co, K * E).t(), conv, dict(M=B * P, K=K * E, a_m=Axis(E, P, sent_stride), a_k=LIN,
+                                                            bias0=b)))
+        convs.append(conv), Ps.append(P), cols.append(col)
         col += Co
+    if grouped:
+        # all filter widths in one grouped GEMM launch + one pooling launch (discriminator_sentiment.py:64-70)
+        ops.gemm_group(calls)
+        for i in range(0, len(convs), 8):
+            ops.act_maxpool_group(convs[i:i + 8], B, Ps[i:i + 8], ACT_RELU, feat, cols[i:i + 8], arg)
+    else:
+        for (a_, b_, c_, kw), P, c0 in zip(calls, Ps, cols):
+            ops.gemm(a_, b_, c_, **kw)
+            ops.act_maxpool(c_, B, P, ACT_RELU, feat, c0, arg)
     return feat, arg

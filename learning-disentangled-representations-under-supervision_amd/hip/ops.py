@@ -78,7 +78,7 @@ def _span_ok(t, base_off, axes_extents):
 
 def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, bias1=None,
          a_m=None, a_k=None, b_k=None, b_n=None, a_exp=None, softmax_bwd=None, force_tile=0, force_splitk=0,
-         dyn=None):
+         dyn=None, _desc_only=False):
     """out[M,N] = epilogue(alpha * A @ B + beta*out + bias0 + bias1).
 
     `a` is viewed as A[M,K] and `b` as B[K,N]; arbitrary 2-D strides (so `w.t()` is free). The optional cgn Axis
@@ -158,6 +158,8 @@ def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, 
     d.workspace_bytes = ws.numel() * 4
     d.force_tile, d.force_splitk = force_tile, force_splitk
     d.dyn_scalars = _ptr(dyn)
+    if _desc_only:
+        return d
     prof = GEMM_PROFILE
     if prof is not None:
         t_, s_, ak, bk = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
@@ -174,6 +176,46 @@ def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, 
     with torch.cuda.device(dev):
         _lib.check(lib.cgn_gemm_f32(_stream(), C.byref(d)), "cgn_gemm_f32")
     return out
+
+
+def gemm_group(calls):
+    """Several independent small products in ONE launch (cgn_gemm_group_f32): calls = [(a, b, out, kwargs), ...] with
+    the arguments of gemm(); 64x64 tiles, no split-K, linear epilogue, equal operand orientations (host-checked by the
+    library). Used for the per-width convolution products of the char-TDNN and the text-CNN."""
+    n = len(calls)
+    if n == 0:
+        return
+    if n > 8:
+        gemm_group(calls[:8])
+        gemm_group(calls[8:])
+        return
+    lib = _lib.load()
+    arr = (GemmDesc * n)()
+    dev = calls[0][2].device
+    for i, (a, b, out, kw) in enumerate(calls):
+        if out.device != dev:
+            raise ValueError("grouped products must live on one device")
+        arr[i] = gemm(a, b, out, _desc_only=True, **kw)
+    with torch.cuda.device(dev):
+        _lib.check(lib.cgn_gemm_group_f32(_stream(), arr, n), "cgn_gemm_group_f32")
+
+
+def act_maxpool_group(convs, B, Ps, act, feat, col0s, arg):
+    """act_maxpool for several widths in one launch: convs[i] [B*Ps[i], Co_i] contiguous -> feat/arg columns
+    col0s[i] .. col0s[i]+Co_i."""
+    n = len(convs)
+    _req(1 <= n <= 8 and len(Ps) == n and len(col0s) == n, "1..8 widths")
+    ldf = _rows2d(feat, "feat")
+    _req(arg.is_cuda and arg.dtype == torch.int32 and arg.is_contiguous() and arg.shape == feat.shape, "arg must be int32")
+    ptrs = (C.c_void_p * n)()
+    P_, Co_, c0_ = (C.c_int32 * n)(), (C.c_int32 * n)(), (C.c_int32 * n)()
+    for i, cv in enumerate(convs):
+        _chk_f32(cv, "conv")
+        _req(cv.is_contiguous() and cv.dim() == 2 and cv.shape[0] == B * Ps[i] and feat.shape[0] == B
+             and feat.shape[1] >= col0s[i] + cv.shape[1], "act_maxpool_group shapes")
+        ptrs[i], P_[i], Co_[i], c0_[i] = cv.data_ptr(), Ps[i], cv.shape[1], col0s[i]
+    _call("cgn_act_maxpool_group_f32", feat.device, n, ptrs, P_, Co_, c0_, B, act, _ptr(feat), ldf, _ptr(arg),
+          arg.stride(0))
 
 
 # bench.py sets this to {"variant": (tile, a_kcontig, b_kcontig) or None, "records": []} to time GEMM launches with
