@@ -105,9 +105,19 @@ struct TileLoader {
     static constexpr int KGROUPS = NT / ROWS;    // !KC: thread groups along k
     static_assert(KC || (BK / KGROUPS == 4 * PER), "k coverage");
 
+    // !KC && VEC ("row-vector" form): memory is contiguous along the row index and rows come in aligned quads, so a
+    // thread loads 4 consecutive rows of ONE k with a 16-byte load (RQ row quads x KG k groups of KP k each) and
+    // transposes on the way into the k-major LDS image (4 x KP-float writes). The scalar form issued 4x the load
+    // instructions and measured 30-55 % slower on every NN / TN product of the step (tools/gemm_bench.py).
+    static constexpr int RQ = ROWS / 4;
+    static constexpr int KG = NT / RQ;
+    static constexpr int KP = BK / KG;
+    static_assert(KC || !VEC || (KP == 2 && KP == PER), "row-vector loader geometry");
+
     f32x4 regs[S][PER];  // S register stages: S tiles of global loads in flight per thread
     long roff[KC ? PER : 1];
     bool rok[KC ? PER : 1];
+    bool rok4[4];
     float rparam[KC ? PER : 1];
 
     __device__ __forceinline__ void init(const Axis& ar, int r0, int rlimit, const float* row_param) {
@@ -123,6 +133,13 @@ struct TileLoader {
                 roff[i] = rok[i] ? axis_off(ar, row) : 0;  // clamped: row 0 of the operand is always addressable
                 rparam[i] = EXP ? row_param[rok[i] ? row : 0] : 0.f;
             }
+        } else if constexpr (VEC) {
+            const int row = r0 + 4 * (tid % RQ);
+            rok[0] = row < rlimit;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rok4[i] = row + i < rlimit;
+            roff[0] = rok[0] ? axis_off(ar, row) : 0;  // a quad never splits a group: rpg % 4 == 0 (host check)
+            rparam[0] = 0.f;
         } else {
             const int row = r0 + tid % ROWS;
             rok[0] = row < rlimit;
@@ -161,6 +178,14 @@ struct TileLoader {
                     for (int j = 0; j < 4; ++j) v[j] = base[roff[i] + koff[j]];
                     regs[st][i] = v;
                 }
+            }
+        } else if constexpr (VEC) {
+            const int kb = k0 + (tid / RQ) * KP;
+            const float* rb = base + roff[0];
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                const int k = kb + j;
+                regs[st][j] = *reinterpret_cast<const f32x4*>(rb + axis_off(ak, k < kend ? k : kbeg));
             }
         } else {
             const int kb = k0 + (tid / ROWS) * (4 * PER);  // wave-uniform
@@ -208,6 +233,17 @@ struct TileLoader {
                 }
                 *reinterpret_cast<f32x4*>(dst + (r + i * RS) * LDK + q * 4) = v;
             }
+        } else if constexpr (VEC) {
+            const int row = 4 * (tid % RQ);
+            const int kl = (tid / RQ) * KP;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x2 v;
+                v[0] = (rok4[i] && k0 + kl < kend) ? regs[st][0][i] : 0.f;
+                v[1] = (rok4[i] && k0 + kl + 1 < kend) ? regs[st][1][i] : 0.f;
+                *reinterpret_cast<f32x2*>(dst + (row + i) * LDK + kl) = v;
+            }
         } else {
             const int row = tid % ROWS;
             const int kl = (tid / ROWS) * (4 * PER);
@@ -235,7 +271,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // S: register stages = K tiles of global loads in flight per thread. Mid-size products of the CGN step have only
 // ~1 block per CU (260-700 tiles), so a wave must cover the L2/HBM round trip (~1-2 us) by itself: with one tile in
 // flight it stalls every K step (0.43 us of MFMA work per step).
-template <int BT, bool A_KC, bool B_KC, bool VEC, bool EXP, int S, int BK>
+// VEC: bit 0 = operand A is read with 16-byte loads, bit 1 = operand B (each along its own contiguous axis)
+template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, const int t) {
     constexpr int TW = BT / 64;  // 32x32 accumulators per wave along each dim
     constexpr int LDK = BK + 4;  // LDS row stride (floats) of both operand images
@@ -261,8 +298,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
     const int wm = wave >> 1, wn = wave & 1;
     const float a_scale = (EXP && p.dyn) ? p.dyn[0] : p.a_scale;
 
-    TileLoader<BT, A_KC, BK, S, VEC, EXP> la;
-    TileLoader<BT, B_KC, BK, S, VEC, false> lb;
+    TileLoader<BT, A_KC, BK, S, (VEC & 1) != 0, EXP> la;
+    TileLoader<BT, B_KC, BK, S, (VEC & 2) != 0, false> lb;
     la.init(p.am, m0, p.M, p.a_row_param);
     lb.init(p.bn, n0, p.N, nullptr);
 
@@ -381,7 +418,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
     }
 }
 
-template <int BT, bool A_KC, bool B_KC, bool VEC, bool EXP, int S, int BK = (BT == 128 ? 16 : 32)>
+template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK = (BT == 128 ? 16 : 32)>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
     // Work item = (K split, tile). Default (order 2): the XCD remap runs over the tile list, m fastest (neighbouring
     // tiles share the B, usually the weight, panel). Orders 0/1 remap over the whole (split, tile) list so that an XCD
@@ -412,7 +449,7 @@ struct GemmGroup {
     int n;
 };
 
-template <int BT, bool A_KC, bool B_KC, bool VEC, int S, int BK = (BT == 128 ? 16 : 32)>
+template <int BT, bool A_KC, bool B_KC, int VEC, int S, int BK = (BT == 128 ? 16 : 32)>
 __global__ __launch_bounds__(NT, 2) void gemm_group_kernel(const GemmGroup g) {
     int j = 0;
     while (j + 1 < g.n && (int)blockIdx.x >= g.tile_end[j]) ++j;  // block-uniform
@@ -475,8 +512,9 @@ bool axis_vec_ok(const cgn_axis& contig, const cgn_axis& other, int n) {
 int g_stages = 0;  // 0 = default; tools/gemm_bench.py overrides it through cgn_debug_set_stages
 int g_order = 2;   // tile-order experiment knob (cgn_debug_set_stages bits 4..7); 2 = default
 
-template <int BT, int S, bool VEC, bool EXP>
+template <int BT, int VEC, bool EXP>
 void launch_v(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
+    constexpr int S = 2;  // register stages (1, 3, 4 were swept in round 1: 2 is best or equal on every step shape)
     if constexpr (EXP) {  // the exp transform needs a k-contiguous A (checked by the caller)
         if (b_kc)
             hipLaunchKernelGGL((gemm_kernel<BT, true, true, VEC, true, S>), grid, dim3(NT), 0, s, p);
@@ -494,26 +532,23 @@ void launch_v(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t 
     }
 }
 
+template <int BT, bool EXP>
+void launch_e(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
+    // each operand is read with 16-byte loads along its contiguous axis when its addressing allows, scalar otherwise
+    switch ((p.a_vec ? 1 : 0) | (p.b_vec ? 2 : 0)) {
+        case 0: launch_v<BT, 0, EXP>(p, a_kc, b_kc, grid, s); break;
+        case 1: launch_v<BT, 1, EXP>(p, a_kc, b_kc, grid, s); break;
+        case 2: launch_v<BT, 2, EXP>(p, a_kc, b_kc, grid, s); break;
+        default: launch_v<BT, 3, EXP>(p, a_kc, b_kc, grid, s); break;
+    }
+}
+
 template <int BT>
 void launch(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
-    // VEC kernels: every k-contiguous operand is read with 16-byte loads; otherwise the all-scalar variant
-    const bool vec = (!a_kc || p.a_vec) && (!b_kc || p.b_vec);
-    const bool ex = p.a_transform == CGN_ATRANS_EXP;
-    if (!vec) {
-        if (ex) launch_v<BT, 2, false, true>(p, a_kc, b_kc, grid, s);
-        else launch_v<BT, 2, false, false>(p, a_kc, b_kc, grid, s);
-        return;
-    }
-    if (ex) {
-        launch_v<BT, 2, true, true>(p, a_kc, b_kc, grid, s);
-        return;
-    }
-    switch (g_stages) {
-        case 1: launch_v<BT, 1, true, false>(p, a_kc, b_kc, grid, s); break;
-        case 3: launch_v<BT, 3, true, false>(p, a_kc, b_kc, grid, s); break;
-        case 4: launch_v<BT, 4, true, false>(p, a_kc, b_kc, grid, s); break;
-        default: launch_v<BT, 2, true, false>(p, a_kc, b_kc, grid, s); break;
-    }
+    if (p.a_transform == CGN_ATRANS_EXP)
+        launch_e<BT, true>(p, a_kc, b_kc, grid, s);
+    else
+        launch_e<BT, false>(p, a_kc, b_kc, grid, s);
 }
 
 // Tile / split-K heuristic: MI355X has 256 CUs and this kernel fits ~3-4 blocks per CU; aim for >= ~512 blocks.
@@ -588,7 +623,7 @@ int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out
 extern "C" int cgn_abi_version(void) { return 2; }
 
 extern "C" void cgn_debug_set_stages(int v) {
-    g_stages = v & 15;
+    g_stages = v & 15;  // kept for ABI stability: the stage count is fixed at 2 since round 1
     g_order = (v >> 4) & 15;
     if (v == 0) g_order = 2;
 }
@@ -638,8 +673,11 @@ static int prepare_gemm(const cgn_gemm_desc* d, GemmParams& p, bool& a_kc, bool&
     p.a_transform = d->a_transform; p.epilogue = d->epilogue;
     p.alpha = d->alpha; p.beta = d->beta; p.a_scale = d->a_scale;
     p.ep_inv_tau = d->ep_inv_tau; p.ep_ce_scale = d->ep_ce_scale;
-    p.a_vec = ((uintptr_t)d->A % 16 == 0) && a_kc && axis_vec_ok(d->a_k, d->a_m, d->K);
-    p.b_vec = ((uintptr_t)d->B % 16 == 0) && b_kc && axis_vec_ok(d->b_k, d->b_n, d->K);
+    // 16-byte loads run along the operand's contiguous axis: k for a k-contiguous operand, the row index otherwise
+    p.a_vec = ((uintptr_t)d->A % 16 == 0) &&
+              (a_kc ? axis_vec_ok(d->a_k, d->a_m, d->K) : axis_vec_ok(d->a_m, d->a_k, d->M));
+    p.b_vec = ((uintptr_t)d->B % 16 == 0) &&
+              (b_kc ? axis_vec_ok(d->b_k, d->b_n, d->K) : axis_vec_ok(d->b_n, d->b_k, d->N));
     p.ws = d->workspace;
     p.dyn = d->dyn_scalars;
     p.order = g_order;
@@ -687,7 +725,7 @@ extern "C" int cgn_gemm_f32(void* stream, const cgn_gemm_desc* d) {
     return CGN_OK;
 }
 
-template <bool VEC>
+template <int VEC>
 static void launch_group(const GemmGroup& g, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s) {
     if (a_kc && b_kc)
         hipLaunchKernelGGL((gemm_group_kernel<64, true, true, VEC, 2>), dim3(blocks), dim3(NT), 0, s, g);
@@ -703,7 +741,7 @@ extern "C" int cgn_gemm_group_f32(void* stream, const cgn_gemm_desc* descs, int3
     CGN_CHECK_ARG(descs && n >= 1 && n <= GROUP_MAX);
     GemmGroup g;
     g.n = 0;
-    bool a_kc0 = false, b_kc0 = false, vec0 = false;
+    bool a_kc0 = false, b_kc0 = false, va = true, vb = true;
     long blocks = 0;
     for (int i = 0; i < n; ++i) {
         const cgn_gemm_desc* d = descs + i;
@@ -713,13 +751,13 @@ extern "C" int cgn_gemm_group_f32(void* stream, const cgn_gemm_desc* descs, int3
         if (rc) return rc;
         CGN_CHECK_ARG(d->a_transform == CGN_ATRANS_NONE && d->epilogue == CGN_EPI_LINEAR);
         if (d->M == 0 || d->N == 0) continue;
-        const bool vec = (!a_kc || p.a_vec) && (!b_kc || p.b_vec);
         if (g.n == 0) {
-            a_kc0 = a_kc; b_kc0 = b_kc; vec0 = vec;
+            a_kc0 = a_kc; b_kc0 = b_kc;
         } else {
             CGN_CHECK_ARG(a_kc == a_kc0 && b_kc == b_kc0);  // one kernel variant per group
-            vec0 = vec0 && vec;                              // the scalar-load variant serves every member
         }
+        va = va && p.a_vec;  // an operand is read with 16-byte loads only if every member allows it
+        vb = vb && p.b_vec;
         p.tiles_m = cgn_cdiv(d->M, 64);
         p.tiles_n = cgn_cdiv(d->N, 64);
         p.splitk = 1;
@@ -732,14 +770,13 @@ extern "C" int cgn_gemm_group_f32(void* stream, const cgn_gemm_desc* descs, int3
         ++g.n;
     }
     if (g.n == 0) return CGN_OK;
-    if (!vec0) {
-        for (int i = 0; i < g.n; ++i) g.p[i].a_vec = g.p[i].b_vec = 0;
-    }
     hipStream_t s = (hipStream_t)stream;
-    if (vec0)
-        launch_group<true>(g, a_kc0, b_kc0, (unsigned)blocks, s);
-    else
-        launch_group<false>(g, a_kc0, b_kc0, (unsigned)blocks, s);
+    switch ((va ? 1 : 0) | (vb ? 2 : 0)) {
+        case 0: launch_group<0>(g, a_kc0, b_kc0, (unsigned)blocks, s); break;
+        case 1: launch_group<1>(g, a_kc0, b_kc0, (unsigned)blocks, s); break;
+        case 2: launch_group<2>(g, a_kc0, b_kc0, (unsigned)blocks, s); break;
+        default: launch_group<3>(g, a_kc0, b_kc0, (unsigned)blocks, s); break;
+    }
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }
