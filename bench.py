@@ -29,11 +29,15 @@ CFG2 = dict(max_word_len=12, max_seq_len=20, word_vocab_size=20000, char_vocab_s
             encoder_rnn_size=512, latent_variable_size=64, decoder_rnn_size=512, decoder_num_layers=2,
             sentiment_kernel_size=(3, 4, 5), sentiment_kernel_num=100)
 BATCH, SEQ = 64, 20
+# BASELINE.json configs[3] shapes (large-vocab stress: vocab 50k, seq len 40, hidden 1024, batch 256/GPU), run in fp32
+# here: a stress / sizing workload selected with --workload cfg4, never the default bench line (bf16 mode is not built)
+CFG4 = dict(CFG2, max_seq_len=40, word_vocab_size=50000, encoder_rnn_size=1024, decoder_rnn_size=1024)
+WORKLOADS = {"cfg2": (CFG2, 64, 20), "cfg4": (CFG4, 256, 40)}
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
-def make_config(Config):
-    kw = dict(CFG2)
+def make_config(Config, cfgd=None):
+    kw = dict(cfgd or CFG2)
     pos = [kw.pop(k) for k in ("max_word_len", "max_seq_len", "word_vocab_size", "char_vocab_size")]
     return Config(*pos, 5e-5, 7.9, 0.1, 0.1, 1.0, **kw)
 
@@ -81,6 +85,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--z-loss", action="store_true", help="include the z-reconstruction pass (calc_z_loss=True)")
     ap.add_argument("--eager", action="store_true", help="issue the step kernel by kernel instead of replaying a hipGraph")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2",
+                    help="cfg2 = BASELINE configs[1] (the metric's workload); cfg4 = configs[3] shapes in fp32 (stress)")
     ap.add_argument("--force-dp", action="store_true",
                     help="single-GPU rehearsal of the data-parallel schedule: a one-rank RCCL group, collectives issued")
     args = ap.parse_args()
@@ -105,8 +111,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    cfg = make_config(Config)
-    ocfg = O.OracleConfig(**CFG2)
+    cfgd, BATCH, SEQ = WORKLOADS[args.workload]
+    cfg = make_config(Config, cfgd)
+    ocfg = O.OracleConfig(**cfgd)
+    if args.workload != "cfg2":
+        args.no_cpu_baseline = True  # the CPU oracle needs minutes per step at this size
     torch.manual_seed(1234)  # identical replicas on every rank
     model = Controlled_Generation_Sentence(cfg, O.synthetic_word_embed(ocfg)).cuda()
     if world > 1 or args.force_dp:
@@ -188,7 +197,7 @@ def main():
         # WRITE_SIZE in separate runs, FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes)
         traffic, traffic_src = None, None
         tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tp):
+        if os.path.exists(tp) and args.workload == "cfg2":
             with open(tp) as f:
                 tj = json.load(f)
             for k, v in tj["kernels"].items():
@@ -205,8 +214,11 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "CGN full wake-sleep training step (disc step + c inference + enc/gen step + 3 Adam), "
-                                   "BASELINE configs[1]: vocab 20k, seq len 20, batch 64/GPU, emb 300, hidden 512, z 64, "
-                                   "fp32, calc_z_loss=%s" % args.z_loss,
+                                   + ("BASELINE configs[1]: vocab 20k, seq len 20, batch 64/GPU, emb 300, hidden 512, "
+                                      "z 64, " if args.workload == "cfg2" else
+                                      "BASELINE configs[3] SHAPES in fp32 (stress, not the metric's workload): vocab 50k, "
+                                      "seq len 40, batch 256/GPU, hidden 1024, z 64, ")
+                                   + "fp32, calc_z_loss=%s" % args.z_loss,
                        "global_batch": world * BATCH, "seq_len": SEQ, "parallelism": "dp%d" % world,
                        "launch": ("hipGraph replay" if world == 1 and not args.force_dp else
                                   "hipGraph segments + eager RCCL all-reduce") if use_graph else "eager"},

@@ -398,6 +398,46 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
     }
 
     // Epilogue. C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    if (p.epilogue == CGN_EPI_SOFTMAX_BWD && p.splitk == 1) {
+        // Fused softmax/CE backward (dlogits written over the logits): per 32-row slab the per-row operands (lse,
+        // rowdot, target) are loaded once and ALL logits of the slab are requested (clamped addresses, no branch)
+        // before the first exp, instead of four dependent loads per output element.
+        const float inv_tau = p.dyn ? p.dyn[0] : p.ep_inv_tau;
+        const float ce_scale = p.dyn ? p.dyn[1] : p.ep_ce_scale;
+#pragma unroll
+        for (int i = 0; i < TW; ++i) {
+            float lse_r[16], rd_r[16], lg[TW][16];
+            int tg_r[16];
+            bool rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                rv[r] = row < p.M;
+                const int rc = rv[r] ? row : 0;
+                lse_r[r] = p.ep_lse[rc];
+                rd_r[r] = p.ep_rowdot[rc];
+                tg_r[r] = (int)p.ep_target[rc];
+#pragma unroll
+                for (int j = 0; j < TW; ++j) {
+                    const int col = n0 + wn * (BT / 2) + j * 32 + fr;
+                    lg[j][r] = p.ep_logits[(long)rc * p.ep_ld + (col < p.N ? col : 0)];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TW; ++j) {
+                const int col = n0 + wn * (BT / 2) + j * 32 + fr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * (BT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    const float pr = expf(lg[j][r] * inv_tau - lse_r[r]);
+                    const float onehot = (tg_r[r] == col) ? 1.f : 0.f;
+                    const float v = pr * (acc[0][i][j][r] - rd_r[r]) * inv_tau + ce_scale * (pr - onehot);
+                    if (rv[r] && col < p.N) p.C[(long)row * p.ldc + col] = v;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TW; ++i) {
 #pragma unroll

@@ -42,7 +42,7 @@ class CGNStep:
         for n, p in named.items():
             if n == "embedding.word_embed.weight":
                 continue  # frozen constant (selfModules/embedding.py:23)
-            if n.startswith("sentiment_discriminator."):
+            if n.startswith("sentiment_discriminator.") or n.startswith("attribute_discriminators."):
                 groups["disc"].append((n, p))
             elif n.startswith("generator."):
                 groups["gen"].append((n, p))
@@ -84,6 +84,12 @@ class CGNStep:
         # graph can be replayed while the schedules (utils/functional.py:28-42) advance.
         self.dynamic = False
         self.dyn = torch.zeros(4, dtype=torch.float32, device=dev)
+        # one text-CNN per attribute of c (the reference: one, `sentiment_discriminator`; BASELINE configs[4]: two)
+        self.disc_prefixes = ["sentiment_discriminator."] + ["attribute_discriminators.%d." % i
+                                                             for i in range(len(model.attribute_discriminators))]
+        if len(self.disc_prefixes) != cfg.c_size:
+            raise ValueError("config.c_size = %d but the model has %d discriminators" % (cfg.c_size,
+                                                                                        len(self.disc_prefixes)))
         self.Ks = list(cfg.sentiment_kernel_size)
         self.Cos = [cfg.sentiment_kernel_num] * len(self.Ks)
 
@@ -177,10 +183,15 @@ class CGNStep:
                      wcat=self._fused("hw%d.w" % l, table), bcat=self._fused("hw%d.b" % l, table))
                 for l in range(self.n_hw)]
 
-    def _conv_params(self, table):
-        w = [table["sentiment_discriminator.convs1.%d.weight" % i] for i in range(len(self.Ks))]
-        b = [table["sentiment_discriminator.convs1.%d.bias" % i] for i in range(len(self.Ks))]
+    def _conv_params(self, table, a=0):
+        pre = self.disc_prefixes[a]
+        w = [table[pre + "convs1.%d.weight" % i] for i in range(len(self.Ks))]
+        b = [table[pre + "convs1.%d.bias" % i] for i in range(len(self.Ks))]
         return w, b
+
+    def _fc_params(self, table, a=0):
+        pre = self.disc_prefixes[a]
+        return table[pre + "fc1.weight"], table[pre + "fc1.bias"]
 
     def _tdnn_kernels(self, table):
         return [table["embedding.TDNN.TDNN_kernel-%d" % i] for i in range(len(self.cfg.kernels))]
@@ -188,59 +199,78 @@ class CGNStep:
     # -------------------------------------------------------------------------------------------------------------
     # discriminator forward on token ids (word table lookup + text-CNN features)
     # -------------------------------------------------------------------------------------------------------------
-    def _disc_features_from_ids(self, ids):
-        P, E = self.P, self.cfg.word_embed_size
+    def _embed_ids(self, ids):
         B, L = ids.shape
-        emb = _new((B * L, E), self.dev)
-        ops.gather_rows(P["embedding.word_embed.weight"], ids.reshape(-1), emb)
-        cw, cb = self._conv_params(P)
-        feat, arg = engine.textcnn_features_fwd(emb, B, L, E, L * E, cw, cb)
-        return emb, feat, arg
+        emb = _new((B * L, self.cfg.word_embed_size), self.dev)
+        ops.gather_rows(self.P["embedding.word_embed.weight"], ids.reshape(-1), emb)
+        return emb
+
+    def _disc_features(self, emb, B, L, a=0):
+        E = self.cfg.word_embed_size
+        cw, cb = self._conv_params(self.P, a)
+        return engine.textcnn_features_fwd(emb, B, L, E, L * E, cw, cb)
 
     def infer_c(self, enc_word, uniform):
-        """model/cgn.py:134-172: c ~ Bernoulli(softmax(D(emb(x)))[:,1]) with the uniform draw given. Returns (c, p1)."""
-        P = self.P
-        B = enc_word.shape[0]
-        _, feat, _ = self._disc_features_from_ids(enc_word)
-        logits, p1, c = _new((B, 2), self.dev), _new((B,), self.dev), _new((B,), self.dev)
-        ops.disc_head(feat, P["sentiment_discriminator.fc1.weight"], P["sentiment_discriminator.fc1.bias"], logits,
-                      p1=p1)
-        ops.bernoulli(p1, uniform, c)
-        return c, p1
+        """model/cgn.py:134-172: c ~ Bernoulli(softmax(D(emb(x)))[:,1]) with the uniform draw given. Returns (c, p1):
+        [B] for one attribute (the reference), [B, C] with one column per discriminator otherwise."""
+        C = self.cfg.c_size
+        B, L = enc_word.shape
+        emb = self._embed_ids(enc_word)
+        c_all, p_all = _new((B, C), self.dev), _new((B, C), self.dev)
+        for a in range(C):
+            feat, _ = self._disc_features(emb, B, L, a)
+            fw, fb = self._fc_params(self.P, a)
+            logits, p1, c = _new((B, 2), self.dev), _new((B,), self.dev), _new((B,), self.dev)
+            ops.disc_head(feat, fw, fb, logits, p1=p1)
+            u = uniform if C == 1 else uniform[:, a].contiguous()
+            ops.bernoulli(p1, u, c)
+            if C == 1:
+                return c, p1
+            ops.copy2d(c.view(B, 1), c_all[:, a:a + 1])
+            ops.copy2d(p1.view(B, 1), p_all[:, a:a + 1])
+        return c_all, p_all
 
     def disc_train(self, opt, x_labelled, y_labelled, x_generated, c_generated, mask_labelled=None,
                    mask_generated=None, train=True, capture=None, step=True):
-        """One discriminator step, model/cgn.py:269-341. Returns the 5-tuple of :341 as 1-element device tensors.
-        step=False stops after the gradients (the data-parallel schedule reduces them and runs Adam later)."""
+        """One discriminator step, model/cgn.py:269-341. Returns the 5-tuple of :341 as 1-element device tensors
+        (summed over the attributes' discriminators when c has more than one). y_labelled / c_generated: [B] int64, or
+        [B, C] with one label column per attribute. step=False stops after the gradients (the data-parallel schedule
+        reduces them and runs Adam later)."""
         cfg, P, G = self.cfg, self.P, self.G
-        E = cfg.word_embed_size
-        W, b = P["sentiment_discriminator.fc1.weight"], P["sentiment_discriminator.fc1.bias"]
-        dW, db = G["sentiment_discriminator.fc1.weight"], G["sentiment_discriminator.fc1.bias"]
-        dcw, dcb = self._conv_params(G)
-        passes = ((x_labelled, y_labelled, mask_labelled, 1.0, 0.0),
-                  (x_generated, c_generated, mask_generated, cfg.lambda_u, cfg.lambda_u * cfg.beta))
-        stats_all = []
-        for i, (x, y, mask, w_ce, w_ent) in enumerate(passes):
-            B, L = x.shape
-            emb, feat, arg = self._disc_features_from_ids(x)
-            logits, dlog, stats = _new((B, 2), self.dev), _new((B, 2), self.dev), _new((2,), self.dev)
-            ops.disc_head(feat, W, b, logits, mask=mask, y=y, w_ce=w_ce, w_ent=w_ent, dlogits=dlog, stats=stats)
-            stats_all.append(stats)
-            if not train:
-                continue
-            beta = 0.0 if i == 0 else 1.0
-            dfeat = _new(tuple(feat.shape), self.dev)
-            ops.disc_head_bwd(feat, W, dlog, mask=mask, beta=beta, dW=dW, db=db, dfeat=dfeat)
-            ops.conv_bwd_dw(self.Ks, self.Cos, ACT_RELU, 0, dcw, dcb, dfeat, None, arg, emb, L * E, B, L, E, beta=beta)
+        E, C = cfg.word_embed_size, cfg.c_size
+        embs = [(self._embed_ids(x), x.shape) for x in (x_labelled, x_generated)]  # shared by every attribute
+        sums = None
+        for a in range(C):
+            W, b = self._fc_params(P, a)
+            dW, db = self._fc_params(G, a)
+            dcw, dcb = self._conv_params(G, a)
+            col = (lambda t_: t_) if C == 1 else (lambda t_: t_[:, a].contiguous())
+            passes = ((embs[0], col(y_labelled), mask_labelled, 1.0, 0.0),
+                      (embs[1], col(c_generated), mask_generated, cfg.lambda_u, cfg.lambda_u * cfg.beta))
+            stats_all = []
+            for i, ((emb, (B, L)), y, mask, w_ce, w_ent) in enumerate(passes):
+                feat, arg = self._disc_features(emb, B, L, a)
+                logits, dlog, stats = _new((B, 2), self.dev), _new((B, 2), self.dev), _new((2,), self.dev)
+                ops.disc_head(feat, W, b, logits, mask=mask, y=y, w_ce=w_ce, w_ent=w_ent, dlogits=dlog, stats=stats)
+                stats_all.append(stats)
+                if not train:
+                    continue
+                beta = 0.0 if i == 0 else 1.0
+                dfeat = _new(tuple(feat.shape), self.dev)
+                ops.disc_head_bwd(feat, W, dlog, mask=mask, beta=beta, dW=dW, db=db, dfeat=dfeat)
+                ops.conv_bwd_dw(self.Ks, self.Cos, ACT_RELU, 0, dcw, dcb, dfeat, None, arg, emb, L * E, B, L, E,
+                                beta=beta)
+            ce_l, ce_g, ent = stats_all[0][0:1], stats_all[1][0:1], stats_all[1][1:2]
+            gen_loss = ops.lincomb([(1.0, ce_g), (cfg.beta, ent)])  # :329
+            total = ops.lincomb([(1.0, ce_l), (cfg.lambda_u, gen_loss)])  # :334
+            cur = (total, ce_l, gen_loss, ce_g, ent)
+            sums = cur if sums is None else tuple(ops.lincomb([(1.0, x), (1.0, y_)]) for x, y_ in zip(sums, cur))
         if train:
             if capture is not None:
                 capture["disc_grads"] = {n: g.clone() for n, g in self.arenas["disc"].grads.items()}
             if step:
                 self._optim_step(opt)
-        ce_l, ce_g, ent = stats_all[0][0:1], stats_all[1][0:1], stats_all[1][1:2]
-        gen_loss = ops.lincomb([(1.0, ce_g), (cfg.beta, ent)])  # :329
-        total = ops.lincomb([(1.0, ce_l), (cfg.lambda_u, gen_loss)])  # :334
-        return total, ce_l, gen_loss, ce_g, ent
+        return sums
 
     # -------------------------------------------------------------------------------------------------------------
     # encoder forward (embedding -> highway -> biLSTM -> mu/logvar); `x_words` None => word part gathered from ids
@@ -427,20 +457,26 @@ class CGNStep:
             d_out_emb = _new((NT, E), dev)
             ops.fill(d_out_emb, 0.0)  # rows t = T-1 stay zero: out_embedding[:, :-1, :] (cgn.py:1108)
         if use_disc:
-            # ---- c reconstruction through the frozen discriminator (cgn.py:1114-1120) ----------------------------
-            cw, cb = self._conv_params(P)
-            feat_d, arg_d = engine.textcnn_features_fwd(out_emb, B, L, E, T * E, cw, cb)  # rows t < L per sentence
-            fcw, fcb = P["sentiment_discriminator.fc1.weight"], P["sentiment_discriminator.fc1.bias"]
-            logits2, dlog2, stats2 = _new((B, 2), dev), _new((B, 2), dev), _new((2,), dev)
-            y_c = _new((B,), dev, torch.int64)
-            ops.float_to_index(cvec[:, 0].contiguous() if C > 1 else cvec.reshape(B), y_c)
-            ops.disc_head(feat_d, fcw, fcb, logits2, y=y_c, w_ce=cfg.lambda_c, dlogits=dlog2, stats=stats2)
-            c_loss = stats2[0:1]
-            if train:
-                dfeat_d = _new(tuple(feat_d.shape), dev)
-                ops.disc_head_bwd(feat_d, fcw, dlog2, dfeat=dfeat_d)
-                ops.conv_bwd_dx(self.Ks, self.Cos, ACT_RELU, 0, [w.view(w.shape[0], -1) for w in cw], dfeat_d, None,
-                                arg_d, B, L, E, d_out_emb, T * E)
+            # ---- c reconstruction through the frozen discriminator(s) (cgn.py:1114-1120) ---------------------------
+            for a in range(C):
+                cw, cb = self._conv_params(P, a)
+                feat_d, arg_d = engine.textcnn_features_fwd(out_emb, B, L, E, T * E, cw, cb)  # rows t < L per sentence
+                fcw, fcb = self._fc_params(P, a)
+                logits2, dlog2, stats2 = _new((B, 2), dev), _new((B, 2), dev), _new((2,), dev)
+                y_c = _new((B,), dev, torch.int64)
+                ops.float_to_index(cvec[:, a].contiguous() if C > 1 else cvec.reshape(B), y_c)
+                ops.disc_head(feat_d, fcw, fcb, logits2, y=y_c, w_ce=cfg.lambda_c, dlogits=dlog2, stats=stats2)
+                c_loss = stats2[0:1] if a == 0 else ops.lincomb([(1.0, c_loss), (1.0, stats2[0:1])])
+                if train:
+                    dfeat_d = _new(tuple(feat_d.shape), dev)
+                    ops.disc_head_bwd(feat_d, fcw, dlog2, dfeat=dfeat_d)
+                    tgt_dx = d_out_emb if a == 0 else _new((NT, E), dev)
+                    if a > 0:
+                        ops.fill(tgt_dx, 0.0)
+                    ops.conv_bwd_dx(self.Ks, self.Cos, ACT_RELU, 0, [w.view(w.shape[0], -1) for w in cw], dfeat_d,
+                                    None, arg_d, B, L, E, tgt_dx, T * E)
+                    if a > 0:
+                        ops.add3d(tgt_dx.view(B, T, E), d_out_emb.view(B, T, E))
         if calc_z_loss:
             # ---- z reconstruction through the encoder (cgn.py:1122-1137) ------------------------------------------
             enc_in2 = ops.new2d(N, Din, dev)

@@ -47,6 +47,11 @@ class Controlled_Generation_Sentence(nn.Module):
         self.sentiment_discriminator = Sentiment_CNN(self.config)
         self.sentiment_discriminator_autograd = [1 if param.requires_grad else 0
                                                  for param in self.sentiment_discriminator.parameters()]
+        # Multi-attribute extension (BASELINE.json configs[4]: c = sentiment + tense, one text-CNN per attribute):
+        # attribute 0 keeps the reference's module; config.c_size = 1 (the reference) leaves this list empty and the
+        # state_dict unchanged.
+        self.attribute_discriminators = nn.ModuleList(
+            [Sentiment_CNN(self.config) for _ in range(getattr(self.config, "c_size", 1) - 1)])
 
         # kld_coef variant: True reproduces the reference under its own interpreter (Python 2 floor division)
         self.kld_py2_floor = True
@@ -113,7 +118,8 @@ class Controlled_Generation_Sentence(nn.Module):
         encoder_word_input = _to_device_long(input_data[0], use_cuda)
         eng = self.step_engine()
         if uniform is None:
-            uniform = t.rand(encoder_word_input.size(0))
+            C_ = getattr(self.config, "c_size", 1)
+            uniform = t.rand(encoder_word_input.size(0)) if C_ == 1 else t.rand(encoder_word_input.size(0), C_)
         c, _ = eng.infer_c(encoder_word_input.contiguous(), uniform.to(eng.dev, t.float32).contiguous())
         return c
 
@@ -125,7 +131,8 @@ class Controlled_Generation_Sentence(nn.Module):
         X = dev_long(data_handler.create_sentiment_batch(batch_X))
         Y = dev_long(np.array(batch_Y))
         GX = dev_long(data_handler.create_sentiment_batch(generated_samples))
-        GY = generated_c.view(-1).long()
+        C_ = getattr(self.config, "c_size", 1)
+        GY = generated_c.view(-1).long() if C_ == 1 else generated_c.view(-1, C_).long()
         GY = (GY.cuda() if use_cuda else GY).contiguous()
         return X, Y, GX, GY
 
@@ -148,8 +155,10 @@ class Controlled_Generation_Sentence(nn.Module):
             _, ce_l, _, ce_g, _ = eng.disc_train(None, X, Y, GX, GY, train=False)
             if not return_accuracy:
                 return ce_l, ce_g
-            c_l, p_l = eng.infer_c(X, t.full((X.size(0),), 0.5, device=eng.dev))   # c = [p1 > 0.5] = argmax
-            c_g, p_g = eng.infer_c(GX, t.full((GX.size(0),), 0.5, device=eng.dev))
+            C_ = getattr(self.config, "c_size", 1)
+            half = lambda n: t.full((n,) if C_ == 1 else (n, C_), 0.5, device=eng.dev)  # noqa: E731
+            c_l, p_l = eng.infer_c(X, half(X.size(0)))   # c = [p1 > 0.5] = argmax
+            c_g, p_g = eng.infer_c(GX, half(GX.size(0)))
             correct = (c_l.long() == Y).sum()
             generated_correct = (c_g.long() == GY).sum()
             return ce_l, ce_g, correct, generated_correct
@@ -221,7 +230,8 @@ class Controlled_Generation_Sentence(nn.Module):
         return [p for p in self.generator.parameters() if p.requires_grad]
 
     def sentiment_discriminator_parameters(self):
-        return [p for p in self.sentiment_discriminator.parameters() if p.requires_grad]
+        return [p for p in self.sentiment_discriminator.parameters() if p.requires_grad] + \
+               [p for p in self.attribute_discriminators.parameters() if p.requires_grad]
 
     def learnable_parameters(self):
         return [p for p in self.parameters() if p.requires_grad]
@@ -237,6 +247,8 @@ class Controlled_Generation_Sentence(nn.Module):
     def discriminator_mode(self, train_mode=True):
         for i, param in enumerate(self.sentiment_discriminator.parameters()):
             param.requires_grad = bool(train_mode and self.sentiment_discriminator_autograd[i])
+        for param in self.attribute_discriminators.parameters():
+            param.requires_grad = bool(train_mode)
 
     def generator_mode(self, train_mode=True):
         for i, param in enumerate(self.generator.parameters()):

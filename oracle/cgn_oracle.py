@@ -239,6 +239,13 @@ class CGN(nn.Module):
         self.e2logvar = nn.Linear(config.encoder_rnn_size * 2, config.latent_variable_size)  # :38
         self.generator = Generator(config)
         self.sentiment_discriminator = Sentiment_CNN(config)
+        # Multi-attribute extension (BASELINE.json configs[4]: c = sentiment + tense, one text-CNN per attribute, after
+        # Hu et al. 2017 §3): attribute 0 keeps the reference's module name; the reference itself has c_size = 1, for
+        # which this list is empty and the state_dict is unchanged. No counterpart in the reference: parity unpinned.
+        self.attribute_discriminators = nn.ModuleList([Sentiment_CNN(config) for _ in range(config.c_size - 1)])
+
+    def discriminators(self):
+        return [self.sentiment_discriminator] + list(self.attribute_discriminators)
 
     # cgn.py:676-686, 1036-1037
     def encoder_params(self):
@@ -251,7 +258,7 @@ class CGN(nn.Module):
         return [p for p in self.generator.parameters() if p.requires_grad]
 
     def sentiment_discriminator_parameters(self):
-        return [p for p in self.sentiment_discriminator.parameters() if p.requires_grad]
+        return [p for d in self.discriminators() for p in d.parameters() if p.requires_grad]
 
     def encode_for_z(self, encoder_input, eps):
         """cgn.py:83-103 with the t.randn draw (:96) passed in as `eps`."""
@@ -284,14 +291,18 @@ def prep_disc_training(model):
     """cgn.py:363-373 (requires_grad toggles; .train()/.eval() only matters for dropout, which is explicit here)."""
     named = dict(model.named_parameters())
     for n in _trainable(model):
-        named[n].requires_grad = n.startswith("sentiment_discriminator.")
+        named[n].requires_grad = _is_disc(n)
+
+
+def _is_disc(n):
+    return n.startswith("sentiment_discriminator.") or n.startswith("attribute_discriminators.")
 
 
 def prep_enc_gen_training(model):
     """cgn.py:385-395."""
     named = dict(model.named_parameters())
     for n in _trainable(model):
-        named[n].requires_grad = not n.startswith("sentiment_discriminator.")
+        named[n].requires_grad = not _is_disc(n)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -303,7 +314,12 @@ def discriminator_forward(model, encoder_word_input, uniform):
         x = model.embedding.get_word_embed(encoder_word_input)  # :163
         logit = model.sentiment_discriminator(x)  # eval mode => no dropout (:151)
         p1 = F.softmax(logit, dim=1)[:, 1]  # :167
-        return (uniform < p1).to(p1.dtype), p1  # :170-172
+        if model.config.c_size == 1:
+            return (uniform < p1).to(p1.dtype), p1  # :170-172
+        # multi-attribute extension: one column of c per discriminator, uniform [B, C]
+        p1s = [p1] + [F.softmax(d(x), dim=1)[:, 1] for d in model.attribute_discriminators]
+        p = torch.stack(p1s, 1)
+        return (uniform < p).to(p.dtype), p
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -315,20 +331,30 @@ def disc_train_step(model, optimizer, x_labelled, y_labelled, x_generated, c_gen
     data_handler.py:87-102), y/c: class indices [B]. mask_*: explicit dropout masks (Sentiment_CNN is in .train()
     here, cgn.py:371). Returns the 5-tuple of cgn.py:341 (as tensors)."""
     cfg = model.config
-    D = model.sentiment_discriminator
-    logit = D(model.embedding.word_embed(x_labelled), mask_labelled)  # :303-304
-    batch_train_ce_loss = F.cross_entropy(logit, y_labelled.long())  # :306
-    logit_generated = D(model.embedding.word_embed(x_generated), mask_generated)  # :315-316
-    log_softmax_generated = F.log_softmax(logit_generated, dim=1)  # :318
-    softmax_generated = torch.exp(log_softmax_generated)  # :319
-    generated_loss_ce = F.nll_loss(log_softmax_generated, c_generated.view(-1).long())  # :320
-    entropy = torch.neg(torch.mean(torch.sum(softmax_generated * log_softmax_generated, 1)))  # :327
-    generated_loss = generated_loss_ce + cfg.beta * entropy  # :329
-    total_loss = batch_train_ce_loss + cfg.lambda_u * generated_loss  # :334
+    C = cfg.c_size
+    total_loss = batch_train_ce_loss = generated_loss = generated_loss_ce = entropy = 0.0
+    for a, D in enumerate(model.discriminators()):  # the reference: one discriminator (a = 0)
+        y_l = y_labelled if C == 1 else y_labelled[:, a]
+        c_g = c_generated.view(-1) if C == 1 else c_generated[:, a]
+        logit = D(model.embedding.word_embed(x_labelled), mask_labelled)  # :303-304
+        ce_l = F.cross_entropy(logit, y_l.long())  # :306
+        logit_generated = D(model.embedding.word_embed(x_generated), mask_generated)  # :315-316
+        log_softmax_generated = F.log_softmax(logit_generated, dim=1)  # :318
+        softmax_generated = torch.exp(log_softmax_generated)  # :319
+        ce_g = F.nll_loss(log_softmax_generated, c_g.long())  # :320
+        ent = torch.neg(torch.mean(torch.sum(softmax_generated * log_softmax_generated, 1)))  # :327
+        gen_l = ce_g + cfg.beta * ent  # :329
+        total_loss = total_loss + ce_l + cfg.lambda_u * gen_l  # :334
+        batch_train_ce_loss, generated_loss = batch_train_ce_loss + ce_l, generated_loss + gen_l
+        generated_loss_ce, entropy = generated_loss_ce + ce_g, entropy + ent
     optimizer.zero_grad()  # :335
     total_loss.backward()  # :336
     if capture is not None:
-        capture["disc_grads"] = {n: p.grad.detach().clone() for n, p in D.named_parameters() if p.grad is not None}
+        capture["disc_grads"] = {n: p.grad.detach().clone()
+                                 for n, p in model.sentiment_discriminator.named_parameters() if p.grad is not None}
+        capture["disc_grads"].update({"attribute_discriminators." + n: p.grad.detach().clone()
+                                      for n, p in model.attribute_discriminators.named_parameters()
+                                      if p.grad is not None})
     optimizer.step()  # :337
     return total_loss, batch_train_ce_loss, generated_loss, generated_loss_ce, entropy
 
@@ -371,7 +397,9 @@ def enc_gen_train_step(model, encoder_optimizer, generator_optimizer, batch, c_t
     out_embedding = torch.mm(softmax_output, model.embedding.word_embed.weight)  # :1106
     out_embedding = out_embedding.view(batch_size, -1, out_embedding.size(1))[:, :-1, :]  # :1108
     c_reconstructed = model.sentiment_discriminator(out_embedding)  # :1114 (eval mode: no dropout)
-    c_loss = F.cross_entropy(c_reconstructed, c.long().view(-1))  # :1117-1118
+    c_loss = F.cross_entropy(c_reconstructed, c.long()[:, 0])  # :1117-1118
+    for a, D in enumerate(model.attribute_discriminators, 1):  # multi-attribute extension: one c-loss per attribute
+        c_loss = c_loss + F.cross_entropy(D(out_embedding), c.long()[:, a])
     total_reconstruction_loss = cfg.lambda_c * c_loss  # :1120
     if calc_z_loss:  # :1122-1137
         encoder_character_embedding = model.embedding.get_character_embed(encoder_character_input)
@@ -435,6 +463,12 @@ def synthetic_batch(cfg, B, L, seed=1234):
         x_generated=torch.randint(0, V - 3, (B, L), generator=g),
         c_generated=torch.randint(0, 2, (B,), generator=g),
     )
+    C = getattr(cfg, "c_size", 1)
+    if C > 1:  # multi-attribute extension: one label / code / uniform column per attribute (column 0 as above)
+        for k, draw in (("c_uniform", lambda: torch.rand(B, generator=g)),
+                        ("y_labelled", lambda: torch.randint(0, 2, (B,), generator=g)),
+                        ("c_generated", lambda: torch.randint(0, 2, (B,), generator=g))):
+            out[k] = torch.stack([out[k]] + [draw() for _ in range(C - 1)], 1)
     return out
 
 
@@ -446,7 +480,7 @@ def wake_sleep_step(model, opts, data, global_step, calc_z_loss=False, masks=Non
     prep_disc_training(model)  # :55
     d_losses = disc_train_step(model, disc_opt, data["x_labelled"], data["y_labelled"], data["x_generated"],
                                data["c_generated"], masks.get("labelled"), masks.get("generated"), capture)  # :57
-    _set_requires_grad(model.sentiment_discriminator.parameters(), False)  # :81
+    _set_requires_grad([p for d in model.discriminators() for p in d.parameters()], False)  # :81
     c_batch, _ = discriminator_forward(model, data["enc_word"], data["c_uniform"])  # :82
     prep_enc_gen_training(model)  # :85
     batch = [data["enc_word"], data["enc_char"], data["dec_word"], None, data["target"]]

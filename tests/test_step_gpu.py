@@ -39,6 +39,15 @@ CFGS = {
     "cfg2": dict(max_word_len=12, max_seq_len=21, word_vocab_size=20000, char_vocab_size=64, word_embed_size=300,
                  encoder_rnn_size=512, latent_variable_size=64, decoder_rnn_size=512, decoder_num_layers=2,
                  sentiment_kernel_size=(3, 4, 5), sentiment_kernel_num=100),
+    # multi-attribute extension (two discriminators, c = [sentiment, tense], filter widths 1..5), small
+    "multi": dict(max_word_len=8, max_seq_len=9, word_vocab_size=203, char_vocab_size=31, word_embed_size=32,
+                  kernels=((1, 5), (2, 7), (3, 6)), encoder_rnn_size=32, latent_variable_size=12, decoder_rnn_size=48,
+                  sentiment_kernel_size=(1, 2, 3, 4, 5), sentiment_kernel_num=7, c_size=2),
+    # BASELINE.json configs[4] at FULL size: the cfg2 model with c = sentiment + tense, two text-CNN discriminators,
+    # filter widths 1-5 x 128 maps
+    "cfg5": dict(max_word_len=12, max_seq_len=21, word_vocab_size=20000, char_vocab_size=64, word_embed_size=300,
+                 encoder_rnn_size=512, latent_variable_size=64, decoder_rnn_size=512, decoder_num_layers=2,
+                 sentiment_kernel_size=(1, 2, 3, 4, 5), sentiment_kernel_num=128, c_size=2),
 }
 
 
@@ -70,8 +79,9 @@ def kink_margin(oracle, data, calc_z, gen_drop=None, gstep=5000):
 
     for lin in oracle.encoder.hw1._nonlinear:
         hooks.append(lin.register_forward_hook(relu_in))
-    for conv in oracle.sentiment_discriminator.convs1:
-        hooks.append(conv.register_forward_hook(pool_in))
+    for disc in oracle.discriminators():
+        for conv in disc.convs1:
+            hooks.append(conv.register_forward_hook(pool_in))
     import torch.nn.functional as F
     with torch.no_grad():
         x = oracle.embedding.char_embed(data["enc_char"].reshape(-1, oracle.config.max_word_len)).transpose(1, 2)
@@ -81,13 +91,15 @@ def kink_margin(oracle, data, calc_z, gen_drop=None, gstep=5000):
                 top = o.topk(2, dim=2)[0]
                 margins.append((top[..., 0] - top[..., 1]).min().item())
         emb = oracle.embedding.word_embed
-        D = oracle.sentiment_discriminator
+        def D(x):
+            for disc in oracle.discriminators():
+                disc(x)
         D(emb(data["x_labelled"])), D(emb(data["x_generated"])), D(emb(data["enc_word"]))
         enc_in = oracle.embedding(data["enc_word"], data["enc_char"])
         z, std, lv, mu = oracle.encode_for_z(enc_in, data["eps"])
         # the soft-embedding passes (c- and z-reconstruction) see the pre-step weights too
         c, _ = O.discriminator_forward(oracle, data["enc_word"], data["c_uniform"])
-        logits, _ = oracle.generator(emb(data["dec_word"]), torch.cat([z, c.view(-1, 1)], 1), gen_drop)
+        logits, _ = oracle.generator(emb(data["dec_word"]), torch.cat([z, c.view(z.shape[0], -1)], 1), gen_drop)
         B = z.shape[0]
         ls = torch.log_softmax(logits.view(-1, logits.shape[-1]) / O.temp_coef(gstep), 1)
         soft = (ls.exp() @ emb.weight).view(B, -1, emb.weight.shape[1])[:, :-1]
@@ -132,7 +144,8 @@ def build(name, dev, seed=0):
 
 
 @pytest.mark.parametrize("name,B,calc_z", [("tiny", 4, False), ("tiny", 5, True), ("odd", 7, True), ("mid", 16, False),
-                                           ("mid", 8, True), ("cfg1", 32, False), ("cfg2", 64, False)])
+                                           ("mid", 8, True), ("cfg1", 32, False), ("cfg2", 64, False), ("multi", 6, True), ("multi", 9, False),
+                                           ("cfg5", 64, False)])
 def test_wake_sleep_step_matches_oracle(dev, name, B, calc_z):
     ocfg, oracle, cfg, model = build(name, dev)
     L = ocfg.max_seq_len - 1
@@ -168,7 +181,7 @@ def test_wake_sleep_step_matches_oracle(dev, name, B, calc_z):
             first_handler = handler
         cap = {}
         model.prep_disc_training()
-        d_h = disc_train(data["x_generated"].tolist(), data["c_generated"].float().view(-1, 1), 0,
+        d_h = disc_train(data["x_generated"].tolist(), data["c_generated"].float().view(B, -1), 0,
                          mask_labelled=masks["labelled"].float().to(dev), mask_generated=masks["generated"].float().to(dev),
                          capture=cap)
         batch = [data["enc_word"].numpy(), data["enc_char"].numpy(), data["dec_word"].numpy(), None,
@@ -194,7 +207,7 @@ def test_wake_sleep_step_matches_oracle(dev, name, B, calc_z):
         for key, okey, prefix in (("disc_grads", "disc_grads", "sentiment_discriminator."),
                                   ("gen_grads", "gen_grads", "generator."), ("enc_grads", "enc_grads", "")):
             for n, gref in cap_o[okey].items():
-                full = n if n.startswith(prefix) else prefix + n
+                full = n if (n.startswith(prefix) or n.startswith("attribute_discriminators.")) else prefix + n
                 assert rel(cap[key][full], gref) < GTOL, (key, full, step, rel(cap[key][full], gref), margin)
         after_o = dict(oracle.named_parameters())
         after_h = dict(model.named_parameters())
