@@ -272,7 +272,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // ~1 block per CU (260-700 tiles), so a wave must cover the L2/HBM round trip (~1-2 us) by itself: with one tile in
 // flight it stalls every K step (0.43 us of MFMA work per step).
 // VEC: bit 0 = operand A is read with 16-byte loads, bit 1 = operand B (each along its own contiguous axis)
-template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK>
+// SMB: the batched softmax-backward epilogue is compiled in (only the dlogits product's variant: inside the shared
+// variant its registers cost the vocabulary projection 10 %).
+template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK, bool SMB = false>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, const int t) {
     constexpr int TW = BT / 64;  // 32x32 accumulators per wave along each dim
     constexpr int LDK = BK + 4;  // LDS row stride (floats) of both operand images
@@ -398,7 +400,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
     }
 
     // Epilogue. C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-    if (p.epilogue == CGN_EPI_SOFTMAX_BWD && p.splitk == 1) {
+    if constexpr (SMB) {
         // Fused softmax/CE backward (dlogits written over the logits): per 32-row slab the per-row operands (lse,
         // rowdot, target) are loaded once and ALL logits of the slab are requested (clamped addresses, no branch)
         // before the first exp, instead of four dependent loads per output element.
@@ -458,7 +460,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
     }
 }
 
-template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK = (BT == 128 ? 16 : 32)>
+template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK = (BT == 128 ? 16 : 32), bool SMB = false>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
     // Work item = (K split, tile). Default (order 2): the XCD remap runs over the tile list, m fastest (neighbouring
     // tiles share the B, usually the weight, panel). Orders 0/1 remap over the whole (split, tile) list so that an XCD
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
         split = w / ntiles;
         t = w - split * ntiles;
     }
-    gemm_tile<BT, A_KC, B_KC, VEC, EXP, S, BK>(p, split, t);
+    gemm_tile<BT, A_KC, B_KC, VEC, EXP, S, BK, SMB>(p, split, t);
 }
 
 // Grouped launch: up to GROUP_MAX independent products (same kernel variant, no split-K) in ONE launch; block b works
@@ -561,6 +563,12 @@ void launch_v(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t 
         else
             hipLaunchKernelGGL((gemm_kernel<BT, true, false, VEC, true, S>), grid, dim3(NT), 0, s, p);
     } else {
+        if constexpr (BT == 128 && VEC == 3) {
+            if (a_kc && b_kc && p.epilogue == CGN_EPI_SOFTMAX_BWD && p.splitk == 1) {
+                hipLaunchKernelGGL((gemm_kernel<BT, true, true, VEC, false, S, 16, true>), grid, dim3(NT), 0, s, p);
+                return;
+            }
+        }
         if (a_kc && b_kc)
             hipLaunchKernelGGL((gemm_kernel<BT, true, true, VEC, false, S>), grid, dim3(NT), 0, s, p);
         else if (a_kc && !b_kc)

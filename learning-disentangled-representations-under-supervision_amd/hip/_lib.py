@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(PKG_DIR, "lib", "libcgn_hip.so")
+LIB_PATH = os.environ.get("CGN_HIP_LIB") or os.path.join(PKG_DIR, "lib", "libcgn_hip.so")  # env: A/B builds
 
 CGN_OK = 0
 CGN_ERR_INVALID_ARG = 1
