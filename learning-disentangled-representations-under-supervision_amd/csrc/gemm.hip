@@ -228,7 +228,9 @@ struct TileLoader {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float x = v[j];
-                    if constexpr (EXP) x = expf(x * scale - rparam[i]);
+                    // hardware exponential (v_exp_f32 on the base-2 argument): ~1e-6 relative, two instructions
+                    // instead of expf's ~15 in the loop that feeds the MFMAs (x <= 0 here: x*scale - lse)
+                    if constexpr (EXP) x = __expf(x * scale - rparam[i]);
                     v[j] = (rok[i] && k + j < kend) ? x : 0.f;
                 }
                 *reinterpret_cast<f32x4*>(dst + (r + i * RS) * LDK + q * 4) = v;
