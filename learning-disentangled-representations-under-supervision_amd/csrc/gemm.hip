@@ -78,7 +78,7 @@ __device__ __forceinline__ float apply_epilogue(const GemmParams& p, int row, in
     if (p.epilogue == CGN_EPI_SOFTMAX_BWD) {
         const float inv_tau = p.dyn ? p.dyn[0] : p.ep_inv_tau;
         const float ce_scale = p.dyn ? p.dyn[1] : p.ep_ce_scale;
-        const float pr = expf(p.ep_logits[(long)row * p.ep_ld + col] * inv_tau - p.ep_lse[row]);
+        const float pr = __expf(p.ep_logits[(long)row * p.ep_ld + col] * inv_tau - p.ep_lse[row]);
         const float onehot = (p.ep_target[row] == (int64_t)col) ? 1.f : 0.f;
         return pr * (acc - p.ep_rowdot[row]) * inv_tau + ce_scale * (pr - onehot);
     }
@@ -433,7 +433,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * (BT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                    const float pr = expf(lg[j][r] * inv_tau - lse_r[r]);
+                    const float pr = __expf(lg[j][r] * inv_tau - lse_r[r]);
                     const float onehot = (tg_r[r] == col) ? 1.f : 0.f;
                     const float v = pr * (acc[0][i][j][r] - rd_r[r]) * inv_tau + ce_scale * (pr - onehot);
                     if (rv[r] && col < p.N) p.C[(long)row * p.ldc + col] = v;
@@ -801,13 +801,14 @@ extern "C" int cgn_gemm_group_f32(void* stream, const cgn_gemm_desc* descs, int3
         if (rc) return rc;
         CGN_CHECK_ARG(d->a_transform == CGN_ATRANS_NONE && d->epilogue == CGN_EPI_LINEAR);
         if (d->M == 0 || d->N == 0) continue;
+        // One kernel variant per group: the orientation flags of the first member are used for all. The scalar
+        // loaders address any strides (orientation only decides which index runs along the lanes), so a member whose
+        // own orientation differs is still computed correctly once 16-byte loads are off for that operand.
         if (g.n == 0) {
             a_kc0 = a_kc; b_kc0 = b_kc;
-        } else {
-            CGN_CHECK_ARG(a_kc == a_kc0 && b_kc == b_kc0);  // one kernel variant per group
         }
-        va = va && p.a_vec;  // an operand is read with 16-byte loads only if every member allows it
-        vb = vb && p.b_vec;
+        va = va && p.a_vec && a_kc == a_kc0;  // 16-byte loads only if every member allows them
+        vb = vb && p.b_vec && b_kc == b_kc0;
         p.tiles_m = cgn_cdiv(d->M, 64);
         p.tiles_n = cgn_cdiv(d->N, 64);
         p.splitk = 1;

@@ -84,6 +84,9 @@ PROTOTYPES = {
     "cgn_beam_topk_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr,
                                   c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "cgn_act_maxpool_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr, c_i64, c_i32, c_ptr, c_i64]),
+    "cgn_pool_bwd_scatter_f32": (c_i32, [c_ptr, C.POINTER(ConvWidths), c_ptr, c_ptr, c_ptr, c_i32, c_i32,
+                                         C.POINTER(c_ptr)]),
+    "cgn_conv_col2im_f32": (c_i32, [c_ptr, c_i32, C.POINTER(c_ptr), C.POINTER(c_i32), c_i32, c_i32, c_i32, c_ptr, c_i64]),
     "cgn_conv_bwd_dx_f32": (c_i32, [c_ptr, C.POINTER(ConvWidths), c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr,
                                     c_i64]),
     "cgn_conv_bwd_dw_f32": (c_i32, [c_ptr, C.POINTER(ConvWidths), c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32,

@@ -78,7 +78,8 @@ def tdnn_conv_bwd(saved, kernels, dfeat, dkernels, need_dx, beta=0.0):
     if not need_dx:
         return None
     dxw = _new((N * Wl, Cc), dfeat.device)
-    ops.conv_bwd_dx(Ks, Cos, ACT_TANH, 1, list(kernels), dfeat, saved["feat"], saved["arg"], N, Wl, Cc, dxw, Wl * Cc)
+    ops.conv_bwd_dx_dense(Ks, Cos, ACT_TANH, 1, list(kernels), dfeat, saved["feat"], saved["arg"], N, Wl, Cc, dxw,
+                          Wl * Cc)
     return dxw
 
 

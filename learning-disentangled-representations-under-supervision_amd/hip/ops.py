@@ -687,3 +687,39 @@ def beam_topk(logits, lse, S, K, first, eos, pad, scores, done, length, tokens, 
     _call("cgn_beam_topk_f32", logits.device, _ptr(logits), logits.stride(0), _ptr(lse), S, K, V, 1 if first else 0,
           int(eos), int(pad), _ptr(scores), _ptr(done), _ptr(length), _ptr(tokens), _ptr(origin), _ptr(src_rows),
           _ptr(hist_tok), _ptr(hist_org))
+
+
+def conv_bwd_dx_dense(Ks, Cos, act, layout, W, dfeat, feat, arg, B, L, E, dx, sent_stride):
+    """Same result as conv_bwd_dx through the dense route (include/cgn_hip.h): scatter the pooled gradient over the
+    convolution outputs, ONE grouped MFMA launch dcols_w = dconv_w @ W_w over the widths, col2im.
+    W[i]: weight of width i, [Co, K*E] rows (layout 0) or [Co, E, K] (layout 1, torch conv1d)."""
+    n = len(Ks)
+    cw = _conv_widths(Ks, Cos, act, layout)
+    _chk_f32(dfeat, "dfeat"), _chk_f32(dx, "dx")
+    _req(dfeat.is_contiguous() and dfeat.shape == (B, cw.F) and arg.dtype == torch.int32 and arg.is_contiguous()
+         and arg.shape == (B, cw.F), "conv_bwd_dx_dense dfeat/arg shapes")
+    if feat is not None:
+        _req(feat.is_contiguous() and feat.shape == (B, cw.F), "feat shape")
+    nelem = dx.untyped_storage().nbytes() // 4 - dx.storage_offset()
+    _req(sent_stride >= L * E and (B - 1) * sent_stride + L * E <= nelem, "dx too small")
+    dev = dx.device
+    dconvs, dcols, calls = [], [], []
+    for i in range(n):
+        K, Co = Ks[i], Cos[i]
+        _req(W[i].numel() == Co * K * E and K <= L and W[i].is_contiguous(), "conv weight %d" % i)
+        P = L - K + 1
+        dc = alloc((B * P, Co), dev)
+        dl = alloc((B * P, K * E), dev)
+        if layout == 0:
+            kw = dict(M=B * P, N=K * E, K=Co, b_k=Axis(K * E, 0, 0), b_n=Axis(1, 0, 0))
+        else:  # element (o, c, j) of [Co, E, K] -> column n = j*E + c
+            kw = dict(M=B * P, N=K * E, K=Co, b_k=Axis(K * E, 0, 0), b_n=Axis(K, E, 1))
+        kw.update(a_m=Axis(Co, 0, 0), a_k=Axis(1, 0, 0))
+        calls.append((dc, W[i], dl, kw))
+        dconvs.append(dc), dcols.append(dl)
+    ptrs = (C.c_void_p * n)(*[t_.data_ptr() for t_ in dconvs])
+    _call("cgn_pool_bwd_scatter_f32", dev, C.byref(cw), _ptr(dfeat), _ptr(feat), _ptr(arg), B, L, ptrs)
+    gemm_group(calls)
+    cptrs = (C.c_void_p * n)(*[t_.data_ptr() for t_ in dcols])
+    Karr = (C.c_int32 * n)(*Ks)
+    _call("cgn_conv_col2im_f32", dev, n, cptrs, Karr, B, L, E, _ptr(dx), sent_stride)

@@ -473,7 +473,7 @@ class CGNStep:
                     tgt_dx = d_out_emb if a == 0 else _new((NT, E), dev)
                     if a > 0:
                         ops.fill(tgt_dx, 0.0)
-                    ops.conv_bwd_dx(self.Ks, self.Cos, ACT_RELU, 0, [w.view(w.shape[0], -1) for w in cw], dfeat_d,
+                    ops.conv_bwd_dx_dense(self.Ks, self.Cos, ACT_RELU, 0, [w.view(w.shape[0], -1) for w in cw], dfeat_d,
                                     None, arg_d, B, L, E, tgt_dx, T * E)
                     if a > 0:
                         ops.add3d(tgt_dx.view(B, T, E), d_out_emb.view(B, T, E))
