@@ -156,3 +156,26 @@ def test_gemm_rejects_bad_args(dev):
     with pytest.raises(ValueError):  # window addressing that would run past the buffer
         ops.gemm(a, torch.zeros(16, 4, device=dev), torch.zeros(8, 4, device=dev), M=8, K=16,
                  a_m=Axis(8, 0, 0), a_k=Axis(1, 0, 0))
+
+
+@pytest.mark.parametrize("layouts", [("nt", "nt", "nt"), ("nn", "nn"), ("nt", "nn", "tn"), ("tn",) * 8])
+def test_gemm_group_matches_single_launches(dev, layouts):
+    """cgn_gemm_group_f32: several products in one launch (members of different shapes, also of different operand
+    orientations: the group then drops to scalar loads) == the same products one by one; exact on integer operands."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(len(layouts))
+    calls, refs, outs = [], [], []
+    for i, layout in enumerate(layouts):
+        M, N, K = 70 + 33 * i, 40 + 28 * i, 24 + 36 * i
+        A = _mk((M, K), g, True)
+        B = _mk((K, N), g, True)
+        bias = _mk((N,), g, True).to(dev)
+        a = A.to(dev) if layout[0] == "n" else A.t().contiguous().to(dev).t()
+        b = B.to(dev) if layout[1] == "n" else B.t().contiguous().to(dev).t()
+        out = torch.full((M, N), float("nan"), device=dev)
+        calls.append((a, b, out, dict(bias0=bias)))
+        refs.append(A.double() @ B.double() + bias.cpu().double())
+        outs.append(out)
+    ops.gemm_group(calls)
+    for out, ref in zip(outs, refs):
+        assert torch.equal(out.cpu().double(), ref)

@@ -257,3 +257,31 @@ def test_small_kernels(dev):
     assert c.tolist() == [1.0, 0.0, 0.0]
     t = ops.lincomb([(79.0, out[0:1]), (0.5, out[1:2])])
     assert abs(t.item() - (79 * out[0].item() + 0.5 * out[1].item())) < 1e-4 * abs(t.item()) + 1e-6
+
+
+@pytest.mark.parametrize("layout,act", [(0, 0), (1, 1)])
+def test_conv_dx_dense_route_matches_sparse_kernel(dev, layout, act):
+    """cgn_pool_bwd_scatter_f32 + grouped product + cgn_conv_col2im_f32 == cgn_conv_bwd_dx_f32 (same sums, other order)."""
+    engine, ops = _mods()
+    B, L, E = 9, 11, 20
+    Ks, Cos = [1, 3, 4, 6], [5, 7, 3, 9]
+    F_ = sum(Cos)
+    g = torch.Generator().manual_seed(11)
+    W = [torch.randn(co, k * E, generator=g).to(dev) if layout == 0 else torch.randn(co, E, k, generator=g).to(dev)
+         for k, co in zip(Ks, Cos)]
+    dfeat = torch.randn(B, F_, generator=g).to(dev)
+    feat = torch.tanh(torch.randn(B, F_, generator=g)).to(dev)
+    arg = torch.zeros(B, F_, dtype=torch.int32)
+    col = 0
+    for k, co in zip(Ks, Cos):
+        arg[:, col:col + co] = torch.randint(-1 if act == 0 else 0, L - k + 1, (B, co), generator=g).int()
+        col += co
+    arg = arg.to(dev)
+    stride = L * E + 8
+    dx_a = torch.full((B * stride,), float("nan"), device=dev)
+    dx_b = torch.full((B * stride,), float("nan"), device=dev)
+    ops.conv_bwd_dx(Ks, Cos, act, layout, W, dfeat, feat if act else None, arg, B, L, E, dx_a, stride)
+    ops.conv_bwd_dx_dense(Ks, Cos, act, layout, W, dfeat, feat if act else None, arg, B, L, E, dx_b, stride)
+    a = dx_a.view(B, stride)[:, :L * E]
+    b = dx_b.view(B, stride)[:, :L * E]
+    assert rel(b, a.double().cpu()) < 1e-6
