@@ -171,7 +171,7 @@ def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, 
                 e0.record()
                 _lib.check(lib.cgn_gemm_f32(_stream(), C.byref(d)), "cgn_gemm_f32")
                 e1.record()
-            prof["records"].append((key, s_.value, M, N, K, e0, e1))
+            prof["records"].append((key + (("smb",) if softmax_bwd is not None else ()), s_.value, M, N, K, e0, e1))
             return out
     with torch.cuda.device(dev):
         _lib.check(lib.cgn_gemm_f32(_stream(), C.byref(d)), "cgn_gemm_f32")
