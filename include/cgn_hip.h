@@ -180,7 +180,8 @@ int cgn_lstm_seq_bwd_persistent_f32(void* stream, const cgn_lstm_bwd_seq* seqs /
  * ---------------------------------------------------------------------------------------------------------- */
 int cgn_beam_topk_f32(void* stream, const float* logits, int64_t ld, const float* lse, int32_t S, int32_t K, int32_t V,
                       int32_t first, int32_t eos, int32_t pad, float* scores, int32_t* done, int32_t* length,
-                      int64_t* tokens, int32_t* origin, int64_t* src_rows, int64_t* hist_tok, int32_t* hist_org);
+                      int64_t* tokens, int32_t* origin, int64_t* src_rows, int64_t* hist_tok, int32_t* hist_org,
+                      float* cand_val /* scratch [S*K*K] */, int32_t* cand_idx /* scratch [S*K*K] */);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Convolution + max-over-time pooling helpers, shared by the text-CNN discriminator

@@ -82,7 +82,7 @@ PROTOTYPES = {
     "cgn_lstm_seq_fwd_persistent_f32": (c_i32, [c_ptr, C.POINTER(LstmFwdSeq), c_i32, c_i32, c_i32, c_i32, c_ptr, c_i64]),
     "cgn_lstm_seq_bwd_persistent_f32": (c_i32, [c_ptr, C.POINTER(LstmBwdSeq), c_i32, c_i32, c_i32, c_i32, c_ptr, c_i64]),
     "cgn_beam_topk_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr,
-                                  c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+                                  c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "cgn_act_maxpool_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr, c_i64, c_i32, c_ptr, c_i64]),
     "cgn_pool_bwd_scatter_f32": (c_i32, [c_ptr, C.POINTER(ConvWidths), c_ptr, c_ptr, c_ptr, c_i32, c_i32,
                                          C.POINTER(c_ptr)]),

@@ -684,9 +684,11 @@ def beam_topk(logits, lse, S, K, first, eos, pad, scores, done, length, tokens, 
                           (hist_org, "hist_org", torch.int32, R)):
         _req(t_.is_cuda and t_.dtype == dt and t_.is_contiguous() and t_.numel() == ne, "%s must be %s[%d]" % (n, dt, ne))
     _req(1 <= K <= 64 and 0 <= eos < V and 0 <= pad < V, "beam_topk arguments")
+    cand_val = alloc((R * K,), logits.device)
+    cand_idx = alloc((R * K,), logits.device, torch.int32)
     _call("cgn_beam_topk_f32", logits.device, _ptr(logits), logits.stride(0), _ptr(lse), S, K, V, 1 if first else 0,
           int(eos), int(pad), _ptr(scores), _ptr(done), _ptr(length), _ptr(tokens), _ptr(origin), _ptr(src_rows),
-          _ptr(hist_tok), _ptr(hist_org))
+          _ptr(hist_tok), _ptr(hist_org), _ptr(cand_val), _ptr(cand_idx))
 
 
 def conv_bwd_dx_dense(Ks, Cos, act, layout, W, dfeat, feat, arg, B, L, E, dx, sent_stride):
