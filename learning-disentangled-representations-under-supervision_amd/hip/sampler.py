@@ -25,85 +25,144 @@ def _new(shape, dev, dtype=torch.float32):
     return ops.alloc(shape, dev, dtype)
 
 
+class _DecodeState:
+    """Static buffers of one (S, K) decode loop, so that a token step can be captured once and replayed."""
+
+    def __init__(self, eng, S, K):
+        cfg, dev = eng.cfg, eng.dev
+        H, nl = cfg.decoder_rnn_size, cfg.decoder_num_layers
+        R = S * K
+        self.S, self.K, self.R = S, K, R
+        z = lambda *shape, dt=torch.float32: torch.zeros(*shape, dtype=dt, device=dev)  # noqa: E731
+        self.zgK = z(R, 4 * H)
+        self.cur = z(R, dt=torch.int64)
+        self.scores = z(R)
+        self.done, self.length = z(S, dt=torch.int32), z(S, dt=torch.int32)
+        self.origin, self.src_rows = z(R, dt=torch.int32), z(R, dt=torch.int64)
+        self.tok_out, self.org_out = z(R, dt=torch.int64), z(R, dt=torch.int32)
+        self.zero_tgt = z(R, dt=torch.int64)
+        self.h = [z(R, H) for _ in range(nl)]
+        self.c = [z(R, H) for _ in range(nl)]
+        self.sent_of_row = torch.arange(R, device=dev, dtype=torch.int64) // K
+        self.graphs = None  # (first-step graph, next-step graph), built on first use
+        self.keep = None
+
+    def reset(self, go, pad):
+        self.cur.fill_(int(pad))  # beam_search.py:37-38
+        self.cur[::self.K] = int(go)
+        for t_ in [self.scores, self.done, self.length] + self.h + self.c:
+            t_.zero_()
+
+
 class BeamSampler:
-    def __init__(self, eng):
+    """use_graph: capture the token step (first / subsequent) into two hipGraphs per (S, K) and replay them; the
+    eager form issues the same kernels one by one."""
+
+    _cache = {}
+
+    def __init__(self, eng, use_graph=True):
         self.eng = eng
+        self.use_graph = use_graph
+
+    def _token_step(self, st, first, eos, pad):
+        """One decode step over all S*K rows, reading and updating the static state in `st`."""
+        eng = self.eng
+        cfg, P, dev = eng.cfg, eng.P, eng.dev
+        E, H, V = cfg.word_embed_size, cfg.decoder_rnn_size, cfg.word_vocab_size
+        nl, R, S, K = cfg.decoder_num_layers, st.R, st.S, st.K
+        emb = _new((R, E), dev)
+        ops.gather_rows(P["embedding.word_embed.weight"], st.cur, emb)  # cgn.py:793
+        x_op = None
+        seqs = []
+        for l in range(nl):  # generator.py:41, one timestep with carried state
+            sq = engine.LstmSeq(R, 1, H, dev, False)
+            sfx = "_l%d" % l
+            W_ih = P["generator.rnn.weight_ih" + sfx]
+            if l == 0:
+                ops.gemm(emb, W_ih[:, :E].t(), sq.xg.view(R, 4 * H), bias0=P["generator.rnn.bias_ih" + sfx],
+                         bias1=P["generator.rnn.bias_hh" + sfx])
+                sq.xg_extra = st.zgK
+            else:
+                hp, hax = x_op
+                ops.gemm(hp, W_ih.t(), sq.xg.view(R, 4 * H), M=R, K=H, a_m=hax, a_k=LIN,
+                         bias0=P["generator.rnn.bias_ih" + sfx], bias1=P["generator.rnn.bias_hh" + sfx])
+            sq.set_initial(st.h[l], st.c[l])
+            engine.lstm_run_fwd([sq], [P["generator.rnn.weight_hh" + sfx]])
+            x_op = sq.hout_operand()
+            seqs.append(sq)
+        hp, hax = x_op
+        logits = _new((R, V), dev)
+        ops.gemm(hp, P["generator.fc.weight"].t(), logits, M=R, K=H, a_m=hax, a_k=LIN,
+                 bias0=P["generator.fc.bias"])  # cgn.py:803
+        lse, _, _ = ops.softmax_nll_fwd(logits, st.zero_tgt, 1.0)  # log_softmax = logits - lse
+        ops.beam_topk(logits, lse, S, K, first, eos, pad, st.scores, st.done, st.length, st.cur, st.origin,
+                      st.src_rows, st.tok_out, st.org_out)
+        # cgn.py:823-838: every beam continues from its parent's state (rows of the [R,2,H] buffers, slot 1)
+        for l, sq in enumerate(seqs):
+            ops.gather_rows(sq.hbuf.view(2 * R, H), st.src_rows, st.h[l])
+            ops.gather_rows(sq.cbuf.view(2 * R, H), st.src_rows, st.c[l])
+
+    def _build_graphs(self, st, go, eos, pad):
+        dev = self.eng.dev
+        stream = torch.cuda.Stream(dev)
+        stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(stream):  # warm-up: kernel loading and per-stream workspaces before capture
+            st.reset(go, pad)
+            self._token_step(st, True, eos, pad)
+            self._token_step(st, False, eos, pad)
+        torch.cuda.current_stream(dev).wait_stream(stream)
+        torch.cuda.synchronize(dev)
+        graphs = []
+        prev_keep, ops.KEEP = ops.KEEP, []
+        try:
+            for first in (True, False):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    self._token_step(st, first, eos, pad)
+                graphs.append(g)
+            st.keep = ops.KEEP
+        finally:
+            ops.KEEP = prev_keep
+        st.graphs = tuple(graphs)
+        st.tokens_key = (go, eos, pad)
 
     def sample(self, seed, seq_len, beam_size, go, eos, pad, n_best=1):
         """seed [S, Z+C] (device fp32). Returns (hyps, scores): hyps[s] = list over n_best of token lists,
         scores[s] = the final beam scores of sentence s, descending (device tensor [K])."""
         eng = self.eng
         cfg, P, dev = eng.cfg, eng.P, eng.dev
-        E, H, V = cfg.word_embed_size, cfg.decoder_rnn_size, cfg.word_vocab_size
-        nl = cfg.decoder_num_layers
+        E, H = cfg.word_embed_size, cfg.decoder_rnn_size
         S, K = seed.shape[0], int(beam_size)
         R = S * K
         if seed.shape[1] != cfg.latent_variable_size + cfg.c_size:
             raise ValueError("seed must be [S, Z + C]")
-        table = P["embedding.word_embed.weight"]
-        Wih0 = P["generator.rnn.weight_ih_l0"]
+        key = (id(eng), S, K)
+        st = BeamSampler._cache.get(key)
+        if st is None:
+            st = BeamSampler._cache[key] = _DecodeState(eng, S, K)
+        graphed = self.use_graph and ops.KEEP is None  # never nest inside another capture
+        if graphed and (st.graphs is None or st.tokens_key != (go, eos, pad)):
+            self._build_graphs(st, go, eos, pad)
         # the [z,c] part of the layer-0 gates: once per call, then one row per beam
         zg = _new((S, 4 * H), dev)
-        ops.gemm(seed.contiguous(), Wih0[:, E:].t(), zg)
-        sent_of_row = torch.arange(R, device=dev, dtype=torch.int64) // K
-        zgK = _new((R, 4 * H), dev)
-        ops.gather_rows(zg, sent_of_row, zgK)
-
-        cur = torch.full((R,), int(pad), dtype=torch.int64, device=dev)  # beam_search.py:37-38
-        cur[::K] = int(go)
-        scores = torch.zeros(R, dtype=torch.float32, device=dev)  # :31
-        done = torch.zeros(S, dtype=torch.int32, device=dev)
-        length = torch.zeros(S, dtype=torch.int32, device=dev)
-        origin = torch.zeros(R, dtype=torch.int32, device=dev)
-        src_rows = torch.zeros(R, dtype=torch.int64, device=dev)
+        ops.gemm(seed.contiguous(), P["generator.rnn.weight_ih_l0"][:, E:].t(), zg)
+        ops.gather_rows(zg, st.sent_of_row, st.zgK)
+        st.reset(go, pad)
         hist_tok = torch.zeros(seq_len, R, dtype=torch.int64, device=dev)
         hist_org = torch.zeros(seq_len, R, dtype=torch.int32, device=dev)
-        zero_tgt = torch.zeros(R, dtype=torch.int64, device=dev)
-        state = [None] * nl  # per layer (h [R,H], c [R,H]) contiguous; None = zero state
-
         for i in range(seq_len):  # cgn.py:786
-            emb = _new((R, E), dev)
-            ops.gather_rows(table, cur, emb)  # cgn.py:793
-            x_op = None
-            seqs = []
-            for l in range(nl):  # generator.py:41, one timestep with carried state
-                sq = engine.LstmSeq(R, 1, H, dev, False)
-                sfx = "_l%d" % l
-                W_ih = P["generator.rnn.weight_ih" + sfx]
-                if l == 0:
-                    ops.gemm(emb, W_ih[:, :E].t(), sq.xg.view(R, 4 * H), bias0=P["generator.rnn.bias_ih" + sfx],
-                             bias1=P["generator.rnn.bias_hh" + sfx])
-                    sq.xg_extra = zgK
-                else:
-                    hp, hax = x_op
-                    ops.gemm(hp, W_ih.t(), sq.xg.view(R, 4 * H), M=R, K=H, a_m=hax, a_k=LIN,
-                             bias0=P["generator.rnn.bias_ih" + sfx], bias1=P["generator.rnn.bias_hh" + sfx])
-                if state[l] is None:
-                    sq.set_initial()
-                else:
-                    sq.set_initial(state[l][0], state[l][1])
-                engine.lstm_run_fwd([sq], [P["generator.rnn.weight_hh" + sfx]])
-                x_op = sq.hout_operand()
-                seqs.append(sq)
-            hp, hax = x_op
-            logits = _new((R, V), dev)
-            ops.gemm(hp, P["generator.fc.weight"].t(), logits, M=R, K=H, a_m=hax, a_k=LIN,
-                     bias0=P["generator.fc.bias"])  # cgn.py:803
-            lse, _, _ = ops.softmax_nll_fwd(logits, zero_tgt, 1.0)  # log_softmax = logits - lse
-            ops.beam_topk(logits, lse, S, K, i == 0, eos, pad, scores, done, length, cur, origin, src_rows,
-                          hist_tok[i], hist_org[i])
-            # cgn.py:823-838: every beam continues from its parent's state (rows of the [R,2,H] buffers, slot 1)
-            for l, sq in enumerate(seqs):
-                h_new, c_new = _new((R, H), dev), _new((R, H), dev)
-                ops.gather_rows(sq.hbuf.view(2 * R, H), src_rows, h_new)
-                ops.gather_rows(sq.cbuf.view(2 * R, H), src_rows, c_new)
-                state[l] = (h_new, c_new)
-            if bool(done.all().item()):  # cgn.py:840-841 (host check per token, as in the reference)
+            if graphed:
+                st.graphs[0 if i == 0 else 1].replay()
+            else:
+                self._token_step(st, i == 0, eos, pad)
+            hist_tok[i].copy_(st.tok_out, non_blocking=True)
+            hist_org[i].copy_(st.org_out, non_blocking=True)
+            if bool(st.done.all().item()):  # cgn.py:840-841 (host check per token, as in the reference)
                 break
 
         # (4) package everything up, cgn.py:872-882: walk the back-pointers (Beam.get_hyp, beam_search.py:121-132)
-        tok_h, org_h, len_h = hist_tok.cpu(), hist_org.cpu(), length.cpu().tolist()
-        sc = scores.view(S, K)
+        tok_h, org_h, len_h = hist_tok.cpu(), hist_org.cpu(), st.length.cpu().tolist()
+        sc = st.scores.clone().view(S, K)
         order = torch.sort(sc, 1, True)[1].cpu()  # sort_best (:101-103); already descending up to ties
         hyps = []
         for s in range(S):

@@ -33,8 +33,13 @@ def _build(dev, eos_bias=0.0, seed=5, scale=3.0):
     return cfg, ocfg, oracle, model, SyntheticDataHandler(cfg, 8, 10)
 
 
+@pytest.mark.parametrize("graphed", [True, False])
 @pytest.mark.parametrize("S,K,eos_bias", [(6, 5, 0.0), (10, 10, 2.5), (3, 1, 0.0), (7, 4, 4.0)])
-def test_beam_sampler_matches_oracle(dev, S, K, eos_bias):
+def test_beam_sampler_matches_oracle(dev, S, K, eos_bias, graphed, monkeypatch):
+    from ldrs_amd.hip import sampler as hs
+    monkeypatch.setattr(hs.BeamSampler, "_cache", {})
+    orig_init = hs.BeamSampler.__init__
+    monkeypatch.setattr(hs.BeamSampler, "__init__", lambda self, eng, use_graph=True: orig_init(self, eng, graphed))
     cfg, ocfg, oracle, model, handler = _build(dev, eos_bias)
     V = ocfg.word_vocab_size
     pad, go, eos = V - 3, V - 2, V - 1
