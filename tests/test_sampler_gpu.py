@@ -87,3 +87,29 @@ def test_train_complete_model_runs_the_whole_wake_sleep_loop(dev):
     moved = [n for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n])]
     assert any(n.startswith("generator.") for n in moved) and any(n.startswith("sentiment_discriminator.") for n in moved)
     assert "embedding.word_embed.weight" not in moved
+
+
+def test_wake_sleep_loop_on_a_text_corpus(dev):
+    """The whole loop on real text through the in-memory BatchLoader / DataHandler (ragged sentences: reversed,
+    left-padded encoder batches, padded discriminator batches, beam-sampled generated batch)."""
+    import numpy as np
+    import ldrs_amd  # noqa: F401
+    from ldrs_amd import train_functions
+    from ldrs_amd.model.cgn import Controlled_Generation_Sentence
+    from ldrs_amd.utils.config import Config
+    from ldrs_amd.utils.data_handler import DataHandler
+    rng = np.random.RandomState(0)
+    words = ["w%d" % i for i in range(60)]
+    sents = [" ".join(rng.choice(words, size=rng.randint(6, 12))) for _ in range(48)]
+    labelled = [" ".join(rng.choice(words, size=rng.randint(6, 12))) for _ in range(60)]
+    handler = DataHandler(sents, labelled, rng.randint(0, 2, size=60).tolist(), batch_size=10, train_lines=40)
+    bl = handler.gen_batch_loader
+    cfg = Config(bl.max_word_len, bl.max_seq_len, bl.words_vocab_size, bl.chars_vocab_size, 1e-3, 7.9, 0.1, 0.1, 1.0,
+                 word_embed_size=24, kernels=((1, 4), (2, 6)), encoder_rnn_size=32, latent_variable_size=8,
+                 decoder_rnn_size=32, sentiment_kernel_size=(3, 4, 5), sentiment_kernel_num=6)
+    torch.manual_seed(1)
+    emb = (torch.rand(bl.words_vocab_size, 24) * 0.5 - 0.25).numpy()
+    model = Controlled_Generation_Sentence(cfg, emb).to(dev)
+    d, eg = train_functions.train_complete_model(model, handler, cfg, True, 0.3, None, None, "t", num_steps=4)
+    vals = [float(x) for x in d] + [float(x) for x in eg]
+    assert all(v == v and abs(v) < 1e6 for v in vals), vals
