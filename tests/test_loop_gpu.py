@@ -1,4 +1,4 @@
-"""GPU: the batched on-device beam sampler (hip/sampler.py, cgn_beam_topk_f32) against the oracle's restatement of
+"""GPU: the sleep-phase sampler, the whole training loop and checkpoints: the batched on-device beam sampler (hip/sampler.py, cgn_beam_topk_f32) against the oracle's restatement of
 sample_from_generator / Beam (model/cgn.py:747-921, utils/beam_search.py) in fp64 on identical weights and seeds:
 identical token sequences, joint log-probabilities within 1e-4."""
 import pytest
@@ -113,3 +113,34 @@ def test_wake_sleep_loop_on_a_text_corpus(dev):
     d, eg = train_functions.train_complete_model(model, handler, cfg, True, 0.3, None, None, "t", num_steps=4)
     vals = [float(x) for x in d] + [float(x) for x in eg]
     assert all(v == v and abs(v) < 1e6 for v in vals), vals
+
+
+def test_checkpoint_round_trip_through_state_dict(dev):
+    """t.save(cgn_model.state_dict()) / load_state_dict (train_functions.py:107-108, main.py:216): the parameters are
+    views into the flat arenas (padded row strides included), the checkpoint must still carry the reference's keys and
+    shapes, reload into a fresh model (before or after its step engine exists) and continue training identically."""
+    import io
+    cfg, ocfg, oracle, model, handler = _build(dev)
+    eng = model.step_engine()
+    opts = dict(disc=eng.new_optimizer("disc"), enc=eng.new_optimizer("enc"), gen=eng.new_optimizer("gen"))
+    data = {k: v.to(dev).contiguous() for k, v in O.synthetic_batch(ocfg, 6, 9, seed=3).items()}
+    eng.wake_sleep(opts, data, 0.5, 0.9)
+    buf = io.BytesIO()
+    torch.save(model.state_dict(), buf)
+    ref_keys = set(oracle.state_dict().keys())
+    sd = torch.load(io.BytesIO(buf.getvalue()), weights_only=True)
+    assert set(sd.keys()) == ref_keys
+    assert all(tuple(sd[k].shape) == tuple(v.shape) for k, v in oracle.state_dict().items())
+    losses = []
+    for late_engine in (False, True):
+        _, _, _, m2, _ = _build(dev, seed=99)  # different initial weights
+        if late_engine:
+            m2.step_engine()  # arenas already built: load_state_dict must write through the views
+        m2.load_state_dict(sd)
+        for (n, p), (_, q) in zip(model.named_parameters(), m2.named_parameters()):
+            assert torch.equal(p, q), n
+        e2 = m2.step_engine()
+        o2 = dict(disc=e2.new_optimizer("disc"), enc=e2.new_optimizer("enc"), gen=e2.new_optimizer("gen"))
+        dl, c, eg = e2.wake_sleep(o2, data, 0.5, 0.9)
+        losses.append([float(x) for x in dl] + [float(x) for x in eg[:4]])
+    assert losses[0] == losses[1]
