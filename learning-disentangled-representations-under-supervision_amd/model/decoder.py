@@ -1,57 +1,47 @@
-"""Legacy unconditioned decoder (the Generator without the structured code c). Same class and signatures as the
-reference's model/decoder.py:8-76; the reference's CGN never instantiates it (cgn.py:13-17), it shares the Generator's
-kernels."""
+"""Legacy unconditioned decoder: the Generator without the structured code c (input = [word embedding | z]).
+
+Drop-in for the reference's model/decoder.py:8-76 — class `Decoder(params)`, sub-modules `rnn` / `fc`,
+`forward(decoder_input, z, drop_prob, initial_state)` and `only_decoder_beam(...)`. The reference's CGN never
+instantiates it (cgn.py:13-17 import only the Generator); it is kept because the north star names the file, and it
+runs on exactly the Generator's kernels (hip/nn.py LSTM / Linear, `_GenInputFn` for the tiled-z concat).
+"""
 import torch.nn as nn
 
 from ..hip import nn as hnn
-from ..utils.functional import parameters_allocation_check
 from .generator import _GenInputFn, _dropout_mask
 
 
 class Decoder(nn.Module):
 
-    legacy_dropout_noop = True
+    legacy_dropout_noop = True  # F.dropout(x, p) of decoder.py:64 is a no-op in the torch versions it targets
 
     def __init__(self, params):
-        super(Decoder, self).__init__()
-
+        super().__init__()
         self.params = params
+        p = params
+        self.rnn = hnn.LSTM(input_size=p.word_embed_size + p.latent_variable_size, hidden_size=p.decoder_rnn_size,
+                            num_layers=p.decoder_num_layers, batch_first=True)
+        self.fc = hnn.Linear(p.decoder_rnn_size, p.word_vocab_size)
 
-        self.rnn = hnn.LSTM(input_size=self.params.latent_variable_size + self.params.word_embed_size,
-                            hidden_size=self.params.decoder_rnn_size,
-                            num_layers=self.params.decoder_num_layers,
-                            batch_first=True)
+    def _check_placement(self, x):
+        if not all(q.is_cuda == x.is_cuda for q in self.parameters()):
+            raise AssertionError('Invalid CUDA options. Parameters should be allocated in the same memory')
 
-        self.fc = hnn.Linear(self.params.decoder_rnn_size, self.params.word_vocab_size)
+    def _rnn_input(self, decoder_input, z, drop_prob):
+        mask = _dropout_mask(decoder_input, drop_prob, self.training, self.legacy_dropout_noop)
+        return _GenInputFn.apply(decoder_input, z, mask)
 
     def only_decoder_beam(self, decoder_input, z, drop_prob, initial_state=None):
-        assert parameters_allocation_check(self), \
-            'Invalid CUDA options. Parameters should be allocated in the same memory'
-        [beam_batch_size, _, _] = decoder_input.size()
-        mask = _dropout_mask(decoder_input, drop_prob, self.training, self.legacy_dropout_noop)
-        # decoder.py:34-35: one latent vector shared by every beam
-        z = z.reshape(1, -1).expand(beam_batch_size, -1)
-        x = _GenInputFn.apply(decoder_input, z, mask)
-        rnn_out, final_state = self.rnn(x, initial_state)
-        return rnn_out, final_state
+        """One LSTM call with carried state for the sampler; a single latent vector is shared by every beam row
+        (decoder.py:34-35). Returns (rnn_out, final_state)."""
+        self._check_placement(decoder_input)
+        rows = decoder_input.size(0)
+        return self.rnn(self._rnn_input(decoder_input, z.reshape(1, -1).expand(rows, -1), drop_prob), initial_state)
 
     def forward(self, decoder_input, z, drop_prob, initial_state=None):
-        """
-        :param decoder_input: [batch_size, seq_len, embed_size]
-        :param z: [batch_size, latent_variable_size]
-        :return: logits [batch_size, seq_len, word_vocab_size], final rnn state
-        """
-        assert parameters_allocation_check(self), \
-            'Invalid CUDA options. Parameters should be allocated in the same memory'
-
-        [batch_size, seq_len, _] = decoder_input.size()
-        mask = _dropout_mask(decoder_input, drop_prob, self.training, self.legacy_dropout_noop)
-        x = _GenInputFn.apply(decoder_input, z, mask)
-
-        rnn_out, final_state = self.rnn(x, initial_state)
-        rnn_out = rnn_out.contiguous().view(-1, self.params.decoder_rnn_size)
-
-        result = self.fc(rnn_out)
-        result = result.view(batch_size, seq_len, self.params.word_vocab_size)
-
-        return result, final_state
+        """decoder_input [B, T, E], z [B, Z] -> (logits [B, T, V], final (h_n, c_n))."""
+        self._check_placement(decoder_input)
+        B, T, _ = decoder_input.shape
+        hidden, final_state = self.rnn(self._rnn_input(decoder_input, z, drop_prob), initial_state)
+        logits = self.fc(hidden.reshape(B * T, self.params.decoder_rnn_size))
+        return logits.view(B, T, self.params.word_vocab_size), final_state

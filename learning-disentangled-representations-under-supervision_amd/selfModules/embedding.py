@@ -41,30 +41,22 @@ class Embedding(nn.Module):
         self.TDNN = TDNN(self.params)
 
     def forward(self, word_input, character_input):
-        """
-        :param word_input: [batch_size, seq_len] tensor of Long type
-        :param character_input: [batch_size, seq_len, max_word_len] tensor of Long type
-        :return: input embedding with shape of [batch_size, seq_len, word_embed_size + sum_depth]
-        """
-        assert word_input.size()[:2] == character_input.size()[:2], \
-            'Word input and character input must have the same sizes, but {} and {} found'.format(
-                word_input.size(), character_input.size())
-
-        word_input = self.word_embed(word_input)
-        character_input = self.get_character_embed(character_input)
-        return _Cat2Fn.apply(word_input, character_input)
+        """word_input [B, L] int64, character_input [B, L, W] int64 -> [B, L, word_embed_size + sum_depth]
+        (word vectors | char-TDNN features), embedding.py:29-55."""
+        if tuple(word_input.shape[:2]) != tuple(character_input.shape[:2]):
+            raise AssertionError('Word input and character input must have the same sizes, but {} and {} found'.format(
+                tuple(word_input.shape), tuple(character_input.shape)))
+        return _Cat2Fn.apply(self.get_word_embed(word_input), self.get_character_embed(character_input))
 
     def get_word_embed(self, word_input):
         return self.word_embed(word_input)
 
     def get_character_embed(self, character_input):
-        """[batch_size, seq_len, max_word_len] long -> [batch_size, seq_len, sum_depth] (embedding.py:60-74)."""
-        [batch_size, seq_len, _] = character_input.size()
-        character_input = character_input.reshape(-1, self.params.max_word_len)
-        character_input = self.char_embed(character_input)
-        character_input = character_input.view(batch_size, seq_len, self.params.max_word_len,
-                                               self.params.char_embed_size)
-        return self.TDNN(character_input)
+        """[B, L, W] int64 -> [B, L, sum_depth]: char table lookup, then the TDNN (embedding.py:60-74)."""
+        B, L, W = character_input.shape
+        p = self.params
+        chars = self.char_embed(character_input.reshape(B * L, W))
+        return self.TDNN(chars.view(B, L, p.max_word_len, p.char_embed_size))
 
 
 class _Cat2Fn(t.autograd.Function):

@@ -1,6 +1,13 @@
-"""Highway layers. Same class, constructor and parameter names as the reference's selfModules/highway.py:6-50
-(`{nonlinear,linear,gate}_module_{i}-{0=weight,1=bias}`); forward/backward run on MFMA GEMMs with a fused gate kernel.
-Only f = relu is implemented on the device (it is the only f the reference uses, model/encoder.py:15)."""
+"""Highway layers on MI355X: per layer  y = g * relu(N x) + (1 - g) * (L x),  g = sigmoid(G x),  run as MFMA GEMMs with
+a fused gate kernel (hip/nn.py `_HighwayFn`; the fused training step stacks N | L | G into one product, hip/engine.py).
+
+Drop-in for the reference's selfModules/highway.py:6-50: class `Highway(size, num_layers, f)`, `forward(x[N, size])`,
+and the reference's unusual parameter registry — the three affine maps of layer i are NOT sub-modules; their weight and
+bias are registered directly on this module as `nonlinear_module_{i}-0/1`, `linear_module_{i}-0/1`,
+`gate_module_{i}-0/1` (0 = weight, 1 = bias), all nonlinear ones first, then linear, then gate. Checkpoints depend on
+those names and on that order, so both are kept. Only f = relu exists on the device (the reference's only use,
+model/encoder.py:15).
+"""
 import math
 
 import torch
@@ -9,56 +16,41 @@ import torch.nn.functional as F
 
 from ..hip import nn as hnn
 
+_BRANCHES = ("nonlinear", "linear", "gate")
 
-def _linear_params(size):
-    w = nn.Parameter(torch.empty(size, size))
-    b = nn.Parameter(torch.empty(size))
-    nn.init.kaiming_uniform_(w, a=math.sqrt(5))
-    bound = 1 / math.sqrt(size)
-    nn.init.uniform_(b, -bound, bound)
-    return [w, b]
+
+def _affine(size):
+    """Weight and bias initialised like nn.Linear(size, size) (what the reference instantiates)."""
+    weight = nn.Parameter(torch.empty(size, size))
+    bias = nn.Parameter(torch.empty(size))
+    nn.init.kaiming_uniform_(weight, a=math.sqrt(5))
+    nn.init.uniform_(bias, -1.0 / math.sqrt(size), 1.0 / math.sqrt(size))
+    return weight, bias
 
 
 class Highway(nn.Module):
     def __init__(self, size, num_layers, f):
-        super(Highway, self).__init__()
-
+        super().__init__()
         if f not in (F.relu, torch.relu):
             raise NotImplementedError("Highway on MI355X implements f = relu (the reference's only use)")
-        self.num_layers = num_layers
-        self.size = size
-
-        # highway.py:13-23: three lists of Linear(size, size), parameters registered under dashed names
-        self.nonlinear = [_linear_params(size) for _ in range(num_layers)]
-        for i, module in enumerate(self.nonlinear):
-            self._add_to_parameters(module, 'nonlinear_module_{}'.format(i))
-
-        self.linear = [_linear_params(size) for _ in range(num_layers)]
-        for i, module in enumerate(self.linear):
-            self._add_to_parameters(module, 'linear_module_{}'.format(i))
-
-        self.gate = [_linear_params(size) for _ in range(num_layers)]
-        for i, module in enumerate(self.gate):
-            self._add_to_parameters(module, 'gate_module_{}'.format(i))
-
-        self.f = f
+        self.size, self.num_layers, self.f = size, num_layers, f
+        # branch-major creation and registration order (nonlinear 0..n-1, linear 0..n-1, gate 0..n-1)
+        for branch in _BRANCHES:
+            maps = [_affine(size) for _ in range(num_layers)]
+            setattr(self, branch, maps)  # plain lists, like the reference's self.nonlinear / self.linear / self.gate
+            for i, (weight, bias) in enumerate(maps):
+                self.register_parameter('%s_module_%d-0' % (branch, i), weight)
+                self.register_parameter('%s_module_%d-1' % (branch, i), bias)
 
     def layer_params(self):
         """Per layer: dict(nw, nb, lw, lb, gw, gb) of Parameters (the layout hip/engine.py expects)."""
-        return [dict(nw=self.nonlinear[l][0], nb=self.nonlinear[l][1], lw=self.linear[l][0], lb=self.linear[l][1],
-                     gw=self.gate[l][0], gb=self.gate[l][1]) for l in range(self.num_layers)]
+        out = []
+        for i in range(self.num_layers):
+            (nw, nb), (lw, lb), (gw, gb) = self.nonlinear[i], self.linear[i], self.gate[i]
+            out.append(dict(nw=nw, nb=nb, lw=lw, lb=lb, gw=gw, gb=gb))
+        return out
 
     def forward(self, x):
-        """
-        :param x: tensor with shape of [batch_size, size]
-        :return: tensor with shape of [batch_size, size]
-        σ(G x) ⨀ f(N x) + (1 - σ(G x)) ⨀ (L x) per layer (highway.py:38-44)
-        """
-        flat = []
-        for p in self.layer_params():
-            flat += [p[k] for k in ("nw", "nb", "lw", "lb", "gw", "gb")]
+        """x [N, size] -> [N, size]."""
+        flat = [p[k] for p in self.layer_params() for k in ("nw", "nb", "lw", "lb", "gw", "gb")]
         return hnn._HighwayFn.apply(x, *flat)
-
-    def _add_to_parameters(self, parameters, name):
-        for i, parameter in enumerate(parameters):
-            self.register_parameter(name='{}-{}'.format(name, i), param=parameter)

@@ -1,42 +1,35 @@
-"""Char-CNN word encoder. Same class/parameter names as the reference's selfModules/tdnn.py:8-52; the convolutions run
-as implicit-GEMM MFMA kernels with a fused tanh + max-over-positions (hip/engine.py: tdnn_conv_fwd / _bwd)."""
-import torch as t
+"""Character-level word encoder (char-CNN / "TDNN") on MI355X: for every kernel width a bias-free 1-D convolution over
+the word's character embeddings, tanh, max over positions; the per-width features are concatenated.
+
+Drop-in for the reference's selfModules/tdnn.py:8-52: class `TDNN(params)`, kernels `[out_dim, char_embed_size, kW]`
+drawn from U(-1, 1) for each `(kW, out_dim)` of `params.kernels` and registered as `TDNN_kernel-{i}` (checkpoint
+names), `forward(x[B, L, W, Cc]) -> [B, L, sum(out_dim)]`. All widths run as ONE grouped MFMA launch plus one pooling
+launch (hip/engine.py `tdnn_conv_fwd`; backward `tdnn_conv_bwd`), wrapped for autograd by hip/nn.py `_TDNNFn`.
+"""
+import torch
 import torch.nn as nn
-from torch.nn import Parameter
 
 from ..hip import nn as hnn
 
 
 class TDNN(nn.Module):
     def __init__(self, params):
-        super(TDNN, self).__init__()
-
+        super().__init__()
         self.params = params
-
-        # tdnn.py:14-16: bias-free kernels [out_dim, char_embed_size, kW], U(-1, 1), registered as TDNN_kernel-{i}
-        self.kernels = [Parameter(t.Tensor(out_dim, self.params.char_embed_size, kW).uniform_(-1, 1))
-                        for kW, out_dim in params.kernels]
-        self._add_to_parameters(self.kernels, 'TDNN_kernel')
+        self.kernels = []
+        for i, (width, maps) in enumerate(params.kernels):
+            kernel = nn.Parameter(torch.empty(maps, params.char_embed_size, width).uniform_(-1, 1))
+            self.register_parameter('TDNN_kernel-%d' % i, kernel)
+            self.kernels.append(kernel)
 
     def forward(self, x):
-        """
-        :param x: tensor with shape [batch_size, max_seq_len, max_word_len, char_embed_size]
-        :return: tensor with shape [batch_size, max_seq_len, depth_sum]
-        """
-        input_size = x.size()
-        assert len(input_size) == 4, \
-            'Wrong input rang, must be equal to 4, but {} found'.format(len(input_size))
-
-        [batch_size, seq_len, word_len, embed_size] = input_size
-
-        assert embed_size == self.params.char_embed_size, \
-            'Wrong embedding size, must be equal to {}, but {} found'.format(self.params.char_embed_size, embed_size)
-        assert word_len == self.params.max_word_len, \
-            'Wrong word length, must be equal to {}, but {} found'.format(self.params.max_word_len, word_len)
-
-        y = hnn._TDNNFn.apply(x.reshape(batch_size * seq_len, word_len, embed_size), *self.kernels)
-        return y.view(batch_size, seq_len, -1)
-
-    def _add_to_parameters(self, parameters, name):
-        for i, parameter in enumerate(parameters):
-            self.register_parameter(name='{}-{}'.format(name, i), param=parameter)
+        """x: [batch, seq_len, max_word_len, char_embed_size] character embeddings -> [batch, seq_len, sum_depth]."""
+        if x.dim() != 4:
+            raise AssertionError('Wrong input rang, must be equal to 4, but {} found'.format(x.dim()))
+        B, L, W, Cc = x.shape
+        want = (self.params.max_word_len, self.params.char_embed_size)
+        if (W, Cc) != want:
+            raise AssertionError('Wrong word length / embedding size, must be equal to {}, but {} found'.format(
+                want, (W, Cc)))
+        words = x.reshape(B * L, W, Cc)  # one "sentence" of W characters per word
+        return hnn._TDNNFn.apply(words, *self.kernels).view(B, L, -1)
