@@ -32,7 +32,7 @@ extern "C" {
 int cgn_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
- * GEMM (fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32): C = epilogue(alpha * A·B [+ beta*C] [+ bias]).
+ * GEMM (fp32 in memory, fp32 accumulate; fp32 or, optionally, bf16 MFMA operands): C = epilogue(alpha * A·B [+ beta*C] [+ bias]).
  * Replaces every nn.Linear / t.mm / LSTM input projection / Conv2d-as-GEMM call site on the path:
  *   selfModules/highway.py:39-42, model/encoder.py:17-21 (W_ih), model/generator.py:17-22,61 (W_ih, fc),
  *   model/cgn.py:91-92 (e2mu/e2logvar), model/cgn.py:1106 (softmax @ E), model/discriminator_sentiment.py:64
@@ -50,6 +50,9 @@ typedef struct cgn_axis {
 
 #define CGN_ATRANS_NONE 0
 #define CGN_ATRANS_EXP 1 /* a(m,k) := exp(a(m,k)*a_scale - a_row_param[m])  (softmax probabilities on the fly) */
+
+#define CGN_COMPUTE_F32 0
+#define CGN_COMPUTE_BF16 1
 
 #define CGN_EPI_LINEAR 0      /* C = alpha*acc + beta*C + bias0[n] + bias1[n] */
 #define CGN_EPI_SOFTMAX_BWD 1 /* see cgn_gemm_desc.ep_* */
@@ -85,6 +88,12 @@ typedef struct cgn_gemm_desc {
      * transform) and ep_inv_tau read [0] and ep_ce_scale reads [1] at run time, so a captured hipGraph of the step
      * can be replayed while the temperature schedule (utils/functional.py:35-42) advances. */
     const float* dyn_scalars;
+    /* Operand type of the product (the optional bf16 mode): CGN_COMPUTE_F32 = exact fp32 (v_mfma_f32_32x32x2_f32);
+     * CGN_COMPUTE_BF16 = A (after a_transform) and B are rounded to bf16 (nearest-even) as they are staged into LDS
+     * and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation. Memory operands, bias, epilogue, split-K
+     * slabs and C stay fp32 in both modes. */
+    int32_t compute;
+    int32_t reserved0; /* must be 0 */
 } cgn_gemm_desc;
 
 int cgn_gemm_f32(void* stream, const cgn_gemm_desc* desc /* host */);

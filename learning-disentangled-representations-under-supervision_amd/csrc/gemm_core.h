@@ -1,0 +1,686 @@
+// Device templates of the MFMA GEMM (included by gemm.hip: fp32 operands, and gemm_bf16.hip: bf16 operands).
+#pragma once
+#include "common.h"
+
+namespace cgn_gemm {
+
+// Two-level axis, off(i) = (i / rpg) * gs + (i % rpg) * stride, evaluated WITHOUT a branch and without a hardware
+// division (both would sit between the global loads of the K loop, see TileLoader::load): i / rpg is a multiply by
+// magic = ceil(2^40 / rpg) and a shift, exact for i < 2^24 and rpg < 2^16 (checked on the host). A plain axis is the
+// same formula with rpg = 2^30, gs = 0 (i / rpg == 0 for every i < 2^30).
+struct Axis {
+    long stride, gs;
+    unsigned long magic;
+    int rpg;
+};
+
+__device__ __forceinline__ long axis_off(const Axis& a, int i) {
+    const int g = (int)(((unsigned long)(unsigned)i * a.magic) >> 40);
+    return (long)g * a.gs + (long)(i - g * a.rpg) * a.stride;
+}
+
+static inline Axis make_axis(const cgn_axis& c) {
+    Axis a;
+    a.stride = c.stride;
+    if (c.rpg > 0) {
+        a.rpg = (int)c.rpg;
+        a.gs = c.gs;
+        a.magic = ((1UL << 40) + (unsigned long)c.rpg - 1) / (unsigned long)c.rpg;
+    } else {
+        a.rpg = 1 << 30;
+        a.gs = 0;
+        a.magic = 1UL << 10;
+    }
+    return a;
+}
+
+struct GemmParams {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias0;
+    const float* bias1;
+    const float* a_row_param;
+    const float* ep_logits;
+    const float* ep_lse;
+    const float* ep_rowdot;
+    const int64_t* ep_target;
+    float* ws;
+    const float* dyn;  // optional device scalars {inv_tau, ce_scale}: override a_scale/ep_inv_tau and ep_ce_scale
+    long ldc, ep_ld;
+    Axis am, ak, bk, bn;
+    int M, N, K;
+    int k_per_split, splitk;
+    int a_vec, b_vec;
+    int a_transform, epilogue;
+    int tiles_m, tiles_n;
+    int order;  // 0: remap over (split, tile), shorter tile axis fastest; 1: same remap, m fastest; 2: remap over tiles only
+    float alpha, beta, a_scale, ep_inv_tau, ep_ce_scale;
+};
+
+constexpr int g_unroll_mult = 2;
+constexpr int KROUND = 32;  // split-K ranges are multiples of every BK in use
+constexpr int NT = 256;
+
+__device__ __forceinline__ float apply_epilogue(const GemmParams& p, int row, int col, float acc) {
+    if (p.epilogue == CGN_EPI_SOFTMAX_BWD) {
+        const float inv_tau = p.dyn ? p.dyn[0] : p.ep_inv_tau;
+        const float ce_scale = p.dyn ? p.dyn[1] : p.ep_ce_scale;
+        const float pr = __expf(p.ep_logits[(long)row * p.ep_ld + col] * inv_tau - p.ep_lse[row]);
+        const float onehot = (p.ep_target[row] == (int64_t)col) ? 1.f : 0.f;
+        return pr * (acc - p.ep_rowdot[row]) * inv_tau + ce_scale * (pr - onehot);
+    }
+    float v = p.alpha * acc;
+    if (p.bias0) v += p.bias0[col];
+    if (p.bias1) v += p.bias1[col];
+    if (p.beta != 0.f) v += p.beta * p.C[(long)row * p.ldc + col];
+    return v;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// round-to-nearest-even fp32 -> bf16 pairs (hipcc emits v_cvt_pk_bf16_f32 for the casts)
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    bf16x2 v;
+    v[0] = (__bf16)a;
+    v[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ u32x2 pack_bf16x4(const f32x4& v) {
+    u32x2 w;
+    w[0] = pack_bf16x2(v[0], v[1]);
+    w[1] = pack_bf16x2(v[2], v[3]);
+    return w;
+}
+
+// Operand tile loader. The tile is ROWS (m or n index) x BK (k index); its LDS image is row-major [ROWS][LDK] with
+// LDK = BK + 4 floats (144-byte rows): the MFMA loop reads a lane's 4 consecutive k of one row with ONE ds_read_b128
+// (rows 144 B apart put 16 consecutive rows on 16 different 16-byte slots of the 256-byte bank row: conflict-free),
+// and every staging write is a ds_write_b128 of 4 consecutive k of one row.
+//   KC = true : memory is contiguous along k (row-major [rows][k]): thread = (row, k-quad), one float4 load per chunk
+//   KC = false: memory is contiguous along the row index ([k][rows]): thread = one row, lanes run along rows, scalar
+//               loads (a wave covers 64 consecutive rows = 256 contiguous bytes per k), 4 k per chunk
+template <int ROWS, bool KC, int BK, int S, bool VEC, bool EXP, bool BF>
+struct TileLoader {
+    // LDS row stride in 4-byte words: BK + 4 floats, or (BF) BK + 8 bf16: 16 bytes of padding either way
+    static constexpr int LDK = BF ? (BK + 8) / 2 : BK + 4;
+    static constexpr int QUADS = ROWS * BK / 4;  // 4-k chunks per tile
+    static constexpr int PER = QUADS / NT;       // chunks per thread
+    static_assert(QUADS % NT == 0, "tile/threads mismatch");
+    static constexpr int KGROUPS = NT / ROWS;    // !KC: thread groups along k
+    static_assert(KC || (BK / KGROUPS == 4 * PER), "k coverage");
+
+    // !KC && VEC ("row-vector" form): memory is contiguous along the row index and rows come in aligned quads, so a
+    // thread loads 4 consecutive rows of ONE k with a 16-byte load (RQ row quads x KG k groups of KP k each) and
+    // transposes on the way into the k-major LDS image (4 x KP-float writes). The scalar form issued 4x the load
+    // instructions and measured 30-55 % slower on every NN / TN product of the step (tools/gemm_bench.py).
+    static constexpr int RQ = ROWS / 4;
+    static constexpr int KG = NT / RQ;
+    static constexpr int KP = BK / KG;
+    static_assert(KC || !VEC || ((KP == 2 || KP == 4) && KP == PER), "row-vector loader geometry");
+
+    f32x4 regs[S][PER];  // S register stages: S tiles of global loads in flight per thread
+    long roff[KC ? PER : 1];
+    bool rok[KC ? PER : 1];
+    bool rok4[4];
+    float rparam[KC ? PER : 1];
+
+    __device__ __forceinline__ void init(const Axis& ar, int r0, int rlimit, const float* row_param) {
+        const int tid = threadIdx.x;
+        if constexpr (KC) {
+            constexpr int QPR = BK / 4;   // quads per row
+            constexpr int RS = NT / QPR;  // row step between a thread's chunks
+            const int r = tid / QPR;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int row = r0 + r + i * RS;
+                rok[i] = row < rlimit;
+                roff[i] = rok[i] ? axis_off(ar, row) : 0;  // clamped: row 0 of the operand is always addressable
+                rparam[i] = EXP ? row_param[rok[i] ? row : 0] : 0.f;
+            }
+        } else if constexpr (VEC) {
+            const int row = r0 + 4 * (tid % RQ);
+            rok[0] = row < rlimit;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rok4[i] = row + i < rlimit;
+            roff[0] = rok[0] ? axis_off(ar, row) : 0;  // a quad never splits a group: rpg % 4 == 0 (host check)
+            rparam[0] = 0.f;
+        } else {
+            const int row = r0 + tid % ROWS;
+            rok[0] = row < rlimit;
+            roff[0] = rok[0] ? axis_off(ar, row) : 0;
+            rparam[0] = 0.f;
+        }
+    }
+
+    // Issue the global loads of the tile whose first k is k0 (k valid in [k0, kend); kbeg = first k of this block).
+    // The code is BRANCH-FREE: every load is unconditional on a clamped (always valid) address and nothing here
+    // consumes the loaded registers, so S tiles of loads stay in flight under the MFMAs. Invalid elements are zeroed
+    // (and the optional exp transform applied) in store(), right before the LDS write. (Any branch around or between
+    // the loads — even a block-uniform one — makes hipcc's wait-count pass fall back to vmcnt(0) at the next use and
+    // serialises the L2 round trips; measured: 1.25 us per K step for a lone block.)
+    //   VEC: one 16-byte load per chunk. A quad may straddle kend only at the end of the contiguous axis, where the
+    //        host has checked that the padded row stride covers it; quads wholly beyond kend re-read the quad at kbeg.
+    __device__ __forceinline__ void load(int st, const float* __restrict__ base, const Axis& ak, int k0, int kbeg,
+                                         int kend) {
+        const int tid = threadIdx.x;
+        if constexpr (KC) {
+            constexpr int QPR = BK / 4;
+            const int q = tid % QPR;
+            const int k = k0 + q * 4;
+            if constexpr (VEC) {
+                const long koff = axis_off(ak, k < kend ? k : kbeg);
+#pragma unroll
+                for (int i = 0; i < PER; ++i) regs[st][i] = *reinterpret_cast<const f32x4*>(base + roff[i] + koff);
+            } else {
+                long koff[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) koff[j] = axis_off(ak, min(k + j, kend - 1));
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = base[roff[i] + koff[j]];
+                    regs[st][i] = v;
+                }
+            }
+        } else if constexpr (VEC) {
+            const int kb = k0 + (tid / RQ) * KP;
+            const float* rb = base + roff[0];
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                const int k = kb + j;
+                regs[st][j] = *reinterpret_cast<const f32x4*>(rb + axis_off(ak, k < kend ? k : kbeg));
+            }
+        } else {
+            const int kb = k0 + (tid / ROWS) * (4 * PER);  // wave-uniform
+            const float* rb = base + roff[0];
+            // consecutive k: one magic division, then step (group, rest) by one with a select
+            const int kf = min(kb, kend - 1);
+            int g = (int)(((unsigned long)(unsigned)kf * ak.magic) >> 40);
+            int r = kf - g * ak.rpg;
+            int kk = kf;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = rb[(long)g * ak.gs + (long)r * ak.stride];
+                    const bool adv = kk < kend - 1;  // clamp at the last valid k
+                    kk += adv ? 1 : 0;
+                    r += adv ? 1 : 0;
+                    const bool wrap = r == ak.rpg;
+                    g += wrap ? 1 : 0;
+                    r = wrap ? 0 : r;
+                }
+                regs[st][i] = v;
+            }
+        }
+    }
+
+    // Mask/transform the staged registers and write them into the LDS image dst[ROWS][LDK].
+    __device__ __forceinline__ void store(int st, float* __restrict__ dst, int k0, int kend, float scale) const {
+        const int tid = threadIdx.x;
+        if constexpr (KC) {
+            constexpr int QPR = BK / 4;
+            constexpr int RS = NT / QPR;
+            const int q = tid % QPR;
+            const int r = tid / QPR;
+            const int k = k0 + q * 4;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                f32x4 v = regs[st][i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = v[j];
+                    // hardware exponential (v_exp_f32 on the base-2 argument): ~1e-6 relative, two instructions
+                    // instead of expf's ~15 in the loop that feeds the MFMAs (x <= 0 here: x*scale - lse)
+                    if constexpr (EXP) x = __expf(x * scale - rparam[i]);
+                    v[j] = (rok[i] && k + j < kend) ? x : 0.f;
+                }
+                if constexpr (BF)
+                    *reinterpret_cast<u32x2*>(dst + (r + i * RS) * LDK + q * 2) = pack_bf16x4(v);
+                else
+                    *reinterpret_cast<f32x4*>(dst + (r + i * RS) * LDK + q * 4) = v;
+            }
+        } else if constexpr (VEC) {
+            const int row = 4 * (tid % RQ);
+            const int kl = (tid / RQ) * KP;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[KP];
+#pragma unroll
+                for (int j = 0; j < KP; ++j) v[j] = (rok4[i] && k0 + kl + j < kend) ? regs[st][j][i] : 0.f;
+                if constexpr (BF) {
+#pragma unroll
+                    for (int j = 0; j < KP; j += 2)
+                        reinterpret_cast<unsigned*>(dst)[(row + i) * LDK + (kl + j) / 2] = pack_bf16x2(v[j], v[j + 1]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < KP; j += 2) {
+                        f32x2 w;
+                        w[0] = v[j];
+                        w[1] = v[j + 1];
+                        *reinterpret_cast<f32x2*>(dst + (row + i) * LDK + kl + j) = w;
+                    }
+                }
+            }
+        } else {
+            const int row = tid % ROWS;
+            const int kl = (tid / ROWS) * (4 * PER);
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                f32x4 v = regs[st][i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (rok[0] && k0 + kl + 4 * i + j < kend) ? v[j] : 0.f;
+                if constexpr (BF)
+                    *reinterpret_cast<u32x2*>(dst + row * LDK + (kl + 4 * i) / 2) = pack_bf16x4(v);
+                else
+                    *reinterpret_cast<f32x4*>(dst + row * LDK + kl + 4 * i) = v;
+            }
+        }
+    }
+};
+
+// XCD-aware bijective remap: blocks with equal (bid % 8) share an XCD's L2 (observed round-robin dispatch), so
+// give each of the 8 residue classes one contiguous chunk of the tile list.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg / 8, r = nwg % 8;
+    const int xcd = bid % 8, idx = bid / 8;
+    const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
+}
+
+// BK: 16 for the 128-tile (3 blocks/CU by LDS and registers), 32 for the 64-tile (measured, tools/gemm_bench.py).
+// S: register stages = K tiles of global loads in flight per thread. Mid-size products of the CGN step have only
+// ~1 block per CU (260-700 tiles), so a wave must cover the L2/HBM round trip (~1-2 us) by itself: with one tile in
+// flight it stalls every K step (0.43 us of MFMA work per step).
+// VEC: bit 0 = operand A is read with 16-byte loads, bit 1 = operand B (each along its own contiguous axis)
+// SMB: the batched softmax-backward epilogue is compiled in (only the dlogits product's variant: inside the shared
+// variant its registers cost the vocabulary projection 10 %).
+template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK, bool SMB = false, bool BF = false>
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, const int t) {
+    constexpr int TW = BT / 64;  // 32x32 accumulators per wave along each dim
+    constexpr int LDK = BF ? (BK + 8) / 2 : BK + 4;  // LDS row stride (4-byte words) of both operand images
+    // One LDS array (both operands, two buffers): keeps every carve offset explicit and 16-byte aligned.
+    constexpr int TILE = BT * LDK;  // floats per operand image
+    __shared__ __attribute__((aligned(16))) float lds[4 * TILE];
+
+    int tile_m, tile_n;
+    if (p.order == 0 && p.tiles_n < p.tiles_m) {
+        tile_n = t % p.tiles_n;
+        tile_m = t / p.tiles_n;
+    } else {
+        tile_m = t % p.tiles_m;
+        tile_n = t / p.tiles_m;
+    }
+    const int m0 = tile_m * BT, n0 = tile_n * BT;
+
+    const int kbeg = split * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const float a_scale = (EXP && p.dyn) ? p.dyn[0] : p.a_scale;
+
+    TileLoader<BT, A_KC, BK, S, (VEC & 1) != 0, EXP, BF> la;
+    TileLoader<BT, B_KC, BK, S, (VEC & 2) != 0, false, BF> lb;
+    la.init(p.am, m0, p.M, p.a_row_param);
+    lb.init(p.bn, n0, p.N, nullptr);
+
+    // the 64-tile has one 32x32 output per wave: two accumulator chains (even / odd k) halve the dependent-MFMA chain
+    constexpr int NC = (TW == 1) ? 2 : 1;
+    f32x16 acc[NC][TW][TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+#pragma unroll
+        for (int j = 0; j < TW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c][i][j][r] = 0.f;
+
+    // Pipeline (one barrier per K step, LDS double-buffered, S tiles of global loads in flight):
+    //   tile j lives in register stage j % S from its load until it is written to LDS buffer j & 1
+    //   step kt:  write tile kt+1 (loaded during step kt-S) into buf[(kt+1)&1]
+    //             issue the global loads of tile kt+1+S into the stage just freed
+    //             MFMAs on buf[kt&1]
+    //             barrier
+    // The loop is unrolled by U = lcm(S, 2) so that stage and buffer indices are compile-time constants.
+    // Loads and LDS writes past the last tile are not skipped (that would need a branch, see TileLoader::load): they
+    // re-read the block's first quads (L1/L2 hits) and write a buffer nobody reads again.
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            la.load(j, p.A, p.ak, kbeg + j * BK, kbeg, kend);
+            lb.load(j, p.B, p.bk, kbeg + j * BK, kbeg, kend);
+        }
+        la.store(0, lds, kbeg, kend, a_scale);
+        lb.store(0, lds + TILE, kbeg, kend, 0.f);
+        la.load(0, p.A, p.ak, kbeg + S * BK, kbeg, kend);
+        lb.load(0, p.B, p.bk, kbeg + S * BK, kbeg, kend);
+    }
+    __syncthreads();
+
+    const int fr = lane & 31;  // fragment row/col
+    const int fk = lane >> 5;  // k-slice within the 32x32x2 step
+    // U steps per trip, a multiple of lcm(S, 2): hipcc's wait-count pass is exact inside the unrolled body but
+    // waits for ALL outstanding loads at the first LDS store after the loop header, so make trips long.
+    constexpr int U = g_unroll_mult * ((S % 2 == 0) ? S : 2 * S);
+    for (int kt0 = 0; kt0 < nk; kt0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kt = kt0 + u;
+            if (kt >= nk) break;  // block-uniform
+            const float* As = lds + (u & 1) * 2 * TILE;
+            const float* Bs = As + TILE;
+            {
+                const int st = (u + 1) % S;
+                float* An = lds + ((u + 1) & 1) * 2 * TILE;
+                const int k1 = kbeg + (kt + 1) * BK;
+                la.store(st, An, k1, kend, a_scale);
+                lb.store(st, An + TILE, k1, kend, 0.f);
+                la.load(st, p.A, p.ak, k1 + S * BK, kbeg, kend);
+                lb.load(st, p.B, p.bk, k1 + S * BK, kbeg, kend);
+            }
+            if constexpr (BF) {
+                // bf16 operands: a lane's fragment of one 32x32x16 step is 8 consecutive k of its row = ONE 16-byte LDS
+                // read (row stride 2*BK + 16 bytes: 16 consecutive rows fall on 16 different 16-byte slots).
+                const unsigned* ap = reinterpret_cast<const unsigned*>(As) + (wm * (BT / 2) + fr) * LDK + 4 * fk;
+                const unsigned* bp = reinterpret_cast<const unsigned*>(Bs) + (wn * (BT / 2) + fr) * LDK + 4 * fk;
+                bf16x8 a8[BK / 16][TW], b8[BK / 16][TW];
+#pragma unroll
+                for (int jb = 0; jb < BK / 16; ++jb) {
+#pragma unroll
+                    for (int i = 0; i < TW; ++i)
+                        a8[jb][i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * LDK + jb * 8);
+#pragma unroll
+                    for (int j = 0; j < TW; ++j)
+                        b8[jb][j] = *reinterpret_cast<const bf16x8*>(bp + j * 32 * LDK + jb * 8);
+                }
+#pragma unroll
+                for (int jb = 0; jb < BK / 16; ++jb)
+#pragma unroll
+                    for (int i = 0; i < TW; ++i)
+#pragma unroll
+                        for (int j = 0; j < TW; ++j)
+                            acc[jb % NC][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[jb][i], b8[jb][j],
+                                                                                         acc[jb % NC][i][j], 0, 0, 0);
+            } else {
+                // K order inside a step: lane half fk of block j holds k = 8j + 4fk + i for the i-th MFMA (any permutation
+                // of k is legal as long as A and B use the same one), so a lane's 4 values are ONE 16-byte LDS read per tile.
+                const float* ap = As + (wm * (BT / 2) + fr) * LDK + 4 * fk;
+                const float* bp = Bs + (wn * (BT / 2) + fr) * LDK + 4 * fk;
+                f32x4 a4[2][TW], b4[2][TW];
+    #pragma unroll
+                for (int i = 0; i < TW; ++i) a4[0][i] = *reinterpret_cast<const f32x4*>(ap + i * 32 * LDK);
+    #pragma unroll
+                for (int j = 0; j < TW; ++j) b4[0][j] = *reinterpret_cast<const f32x4*>(bp + j * 32 * LDK);
+    #pragma unroll
+                for (int jb = 0; jb < BK / 8; ++jb) {
+                    const int cur = jb & 1;
+                    if (jb + 1 < BK / 8) {  // fragments of the next 8-k block are in flight under this block's MFMAs
+    #pragma unroll
+                        for (int i = 0; i < TW; ++i)
+                            a4[cur ^ 1][i] = *reinterpret_cast<const f32x4*>(ap + i * 32 * LDK + (jb + 1) * 8);
+    #pragma unroll
+                        for (int j = 0; j < TW; ++j)
+                            b4[cur ^ 1][j] = *reinterpret_cast<const f32x4*>(bp + j * 32 * LDK + (jb + 1) * 8);
+                    }
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e)
+    #pragma unroll
+                        for (int i = 0; i < TW; ++i)
+    #pragma unroll
+                            for (int j = 0; j < TW; ++j)
+                                acc[e % NC][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[cur][i][e], b4[cur][j][e], acc[e % NC][i][j], 0,
+                                                                                 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    if constexpr (NC == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][0][r] += acc[1][0][0][r];
+    }
+
+    // Epilogue. C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    if constexpr (SMB) {
+        // Fused softmax/CE backward (dlogits written over the logits): per 32-row slab the per-row operands (lse,
+        // rowdot, target) are loaded once and ALL logits of the slab are requested (clamped addresses, no branch)
+        // before the first exp, instead of four dependent loads per output element.
+        const float inv_tau = p.dyn ? p.dyn[0] : p.ep_inv_tau;
+        const float ce_scale = p.dyn ? p.dyn[1] : p.ep_ce_scale;
+#pragma unroll
+        for (int i = 0; i < TW; ++i) {
+            float lse_r[16], rd_r[16], lg[TW][16];
+            int tg_r[16];
+            bool rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                rv[r] = row < p.M;
+                const int rc = rv[r] ? row : 0;
+                lse_r[r] = p.ep_lse[rc];
+                rd_r[r] = p.ep_rowdot[rc];
+                tg_r[r] = (int)p.ep_target[rc];
+#pragma unroll
+                for (int j = 0; j < TW; ++j) {
+                    const int col = n0 + wn * (BT / 2) + j * 32 + fr;
+                    lg[j][r] = p.ep_logits[(long)rc * p.ep_ld + (col < p.N ? col : 0)];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TW; ++j) {
+                const int col = n0 + wn * (BT / 2) + j * 32 + fr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * (BT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    const float pr = __expf(lg[j][r] * inv_tau - lse_r[r]);
+                    const float onehot = (tg_r[r] == col) ? 1.f : 0.f;
+                    const float v = pr * (acc[0][i][j][r] - rd_r[r]) * inv_tau + ce_scale * (pr - onehot);
+                    if (rv[r] && col < p.N) p.C[(long)row * p.ldc + col] = v;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+            const int col = n0 + wn * (BT / 2) + j * 32 + fr;
+            if (col >= p.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (row >= p.M) continue;
+                if (p.splitk > 1) {
+                    p.ws[((long)split * p.M + row) * p.N + col] = acc[0][i][j][r];
+                } else {
+                    p.C[(long)row * p.ldc + col] = apply_epilogue(p, row, col, acc[0][i][j][r]);
+                }
+            }
+        }
+    }
+}
+
+template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK = (BT == 128 ? 16 : 32), bool SMB = false,
+          bool BF = false>
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
+    // Work item = (K split, tile). Default (order 2): the XCD remap runs over the tile list, m fastest (neighbouring
+    // tiles share the B, usually the weight, panel). Orders 0/1 remap over the whole (split, tile) list so that an XCD
+    // owns whole K ranges of a split-K product: that cuts the memory-side fetch of the three tall-K products (PMC:
+    // their 107 MB logits-sized operand is fetched ~4x, profiles/r01_pmc_traffic.txt) but measured no faster to 15 %
+    // slower (tools/gemm_bench.py, GEMM_ORDER=0,1,2): these kernels are not fetch-bound, the Infinity Cache absorbs
+    // the re-reads. Kept as an experiment knob (cgn_debug_set_stages bits 4..7).
+    const int ntiles = p.tiles_m * p.tiles_n;
+    int split, t;
+    if (p.order == 2) {
+        split = blockIdx.y;
+        t = xcd_remap(blockIdx.x, ntiles);
+    } else {
+        const int w = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, ntiles * p.splitk);
+        split = w / ntiles;
+        t = w - split * ntiles;
+    }
+    gemm_tile<BT, A_KC, B_KC, VEC, EXP, S, BK, SMB, BF>(p, split, t);
+}
+
+// Grouped launch: up to GROUP_MAX independent products (same kernel variant, no split-K) in ONE launch; block b works
+// on the product whose tile range contains b. For chains of small same-shaped products (the six char-TDNN widths, the
+// text-CNN's filter widths) the launch boundaries and the drain/fill between them cost more than the arithmetic.
+constexpr int GROUP_MAX = 8;
+struct GemmGroup {
+    GemmParams p[GROUP_MAX];
+    int tile_end[GROUP_MAX];  // running sum of tile counts
+    int n;
+};
+
+template <int BT, bool A_KC, bool B_KC, int VEC, int S, int BK = (BT == 128 ? 16 : 32), bool BF = false>
+__global__ __launch_bounds__(NT, 2) void gemm_group_kernel(const GemmGroup g) {
+    int j = 0;
+    while (j + 1 < g.n && (int)blockIdx.x >= g.tile_end[j]) ++j;  // block-uniform
+    const int t = blockIdx.x - (j ? g.tile_end[j - 1] : 0);
+    gemm_tile<BT, A_KC, B_KC, VEC, false, S, BK, false, BF>(g.p[j], 0, t);
+}
+
+// Sums the split-K slabs in fixed order z = 0..splitk-1 (bitwise reproducible). VEC: four consecutive columns per
+// thread (16-byte slab loads, N % 4 == 0). The slab loads of 4 splits are issued together before they are added: with
+// one load per trip the kernel was a chain of L2 round trips (12.7 us for 16 MB of slabs).
+template <bool VEC>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
+    constexpr int W = VEC ? 4 : 1;
+    const long total = (long)p.M * p.N;
+    const long nvec = total / W;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
+        const long idx = v * W;
+        float s[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) s[j] = 0.f;
+        for (int z0 = 0; z0 < p.splitk; z0 += 4) {
+            float part[4][W];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int z = min(z0 + u, p.splitk - 1);
+                const float* src = p.ws + (long)z * total + idx;
+                if constexpr (VEC) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) part[u][j] = t[j];
+                } else {
+                    part[u][0] = *src;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (z0 + u < p.splitk) {
+#pragma unroll
+                    for (int j = 0; j < W; ++j) s[j] += part[u][j];
+                }
+            }
+        }
+        const int row = (int)(idx / p.N), col = (int)(idx % p.N);
+#pragma unroll
+        for (int j = 0; j < W; ++j) p.C[(long)row * p.ldc + col + j] = apply_epilogue(p, row, col + j, s[j]);
+    }
+}
+
+// BK per (tile, operand type): fp32 16 / 32 (measured, see above); bf16 operands take half the LDS per k and their MFMA
+// covers 16 k, so the K step is doubled (fewer barriers per MFMA).
+template <int BT, bool BF>
+constexpr int bk_of() {
+    return BF ? (BT == 128 ? 32 : 64) : (BT == 128 ? 16 : 32);
+}
+
+template <int BT, int VEC, bool EXP, bool BF>
+void launch_v(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
+    constexpr int S = 2;  // register stages (1, 3, 4 were swept in round 1: 2 is best or equal on every step shape)
+    constexpr int BK = bk_of<BT, BF>();
+    if constexpr (EXP) {  // the exp transform needs a k-contiguous A (checked by the caller)
+        if (b_kc)
+            hipLaunchKernelGGL((gemm_kernel<BT, true, true, VEC, true, S, BK, false, BF>), grid, dim3(NT), 0, s, p);
+        else
+            hipLaunchKernelGGL((gemm_kernel<BT, true, false, VEC, true, S, BK, false, BF>), grid, dim3(NT), 0, s, p);
+    } else {
+        if constexpr (BT == 128 && VEC == 3) {
+            if (a_kc && b_kc && p.epilogue == CGN_EPI_SOFTMAX_BWD && p.splitk == 1) {
+                hipLaunchKernelGGL((gemm_kernel<BT, true, true, VEC, false, S, BK, true, BF>), grid, dim3(NT), 0, s, p);
+                return;
+            }
+        }
+        if (a_kc && b_kc)
+            hipLaunchKernelGGL((gemm_kernel<BT, true, true, VEC, false, S, BK, false, BF>), grid, dim3(NT), 0, s, p);
+        else if (a_kc && !b_kc)
+            hipLaunchKernelGGL((gemm_kernel<BT, true, false, VEC, false, S, BK, false, BF>), grid, dim3(NT), 0, s, p);
+        else if (!a_kc && b_kc)
+            hipLaunchKernelGGL((gemm_kernel<BT, false, true, VEC, false, S, BK, false, BF>), grid, dim3(NT), 0, s, p);
+        else
+            hipLaunchKernelGGL((gemm_kernel<BT, false, false, VEC, false, S, BK, false, BF>), grid, dim3(NT), 0, s, p);
+    }
+}
+
+template <int BT, bool EXP, bool BF>
+void launch_e(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
+    // each operand is read with 16-byte loads along its contiguous axis when its addressing allows, scalar otherwise
+    switch ((p.a_vec ? 1 : 0) | (p.b_vec ? 2 : 0)) {
+        case 0: launch_v<BT, 0, EXP, BF>(p, a_kc, b_kc, grid, s); break;
+        case 1: launch_v<BT, 1, EXP, BF>(p, a_kc, b_kc, grid, s); break;
+        case 2: launch_v<BT, 2, EXP, BF>(p, a_kc, b_kc, grid, s); break;
+        default: launch_v<BT, 3, EXP, BF>(p, a_kc, b_kc, grid, s); break;
+    }
+}
+
+// One product: bt = 64 | 128.
+template <bool BF>
+void launch_gemm(const GemmParams& p, int bt, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
+    const bool ex = p.a_transform == CGN_ATRANS_EXP;
+    if (bt == 128) {
+        if (ex) launch_e<128, true, BF>(p, a_kc, b_kc, grid, s);
+        else launch_e<128, false, BF>(p, a_kc, b_kc, grid, s);
+    } else {
+        if (ex) launch_e<64, true, BF>(p, a_kc, b_kc, grid, s);
+        else launch_e<64, false, BF>(p, a_kc, b_kc, grid, s);
+    }
+}
+
+template <int VEC, bool BF>
+void launch_group_v(const GemmGroup& g, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s) {
+    constexpr int BK = bk_of<64, BF>();
+    if (a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_group_kernel<64, true, true, VEC, 2, BK, BF>), dim3(blocks), dim3(NT), 0, s, g);
+    else if (a_kc && !b_kc)
+        hipLaunchKernelGGL((gemm_group_kernel<64, true, false, VEC, 2, BK, BF>), dim3(blocks), dim3(NT), 0, s, g);
+    else if (!a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_group_kernel<64, false, true, VEC, 2, BK, BF>), dim3(blocks), dim3(NT), 0, s, g);
+    else
+        hipLaunchKernelGGL((gemm_group_kernel<64, false, false, VEC, 2, BK, BF>), dim3(blocks), dim3(NT), 0, s, g);
+}
+
+template <bool BF>
+void launch_group(const GemmGroup& g, int vec, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s) {
+    switch (vec) {
+        case 0: launch_group_v<0, BF>(g, a_kc, b_kc, blocks, s); break;
+        case 1: launch_group_v<1, BF>(g, a_kc, b_kc, blocks, s); break;
+        case 2: launch_group_v<2, BF>(g, a_kc, b_kc, blocks, s); break;
+        default: launch_group_v<3, BF>(g, a_kc, b_kc, blocks, s); break;
+    }
+}
+
+}  // namespace cgn_gemm
+
+// Defined in gemm.hip (fp32 operands) and gemm_bf16.hip (bf16 operands): one translation unit per operand type keeps the
+// two sets of kernel variants compiling in parallel.
+namespace cgn_gemm {
+void launch_gemm_f32ops(const GemmParams& p, int bt, bool a_kc, bool b_kc, dim3 grid, hipStream_t s);
+void launch_gemm_bf16ops(const GemmParams& p, int bt, bool a_kc, bool b_kc, dim3 grid, hipStream_t s);
+void launch_group_f32ops(const GemmGroup& g, int vec, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s);
+void launch_group_bf16ops(const GemmGroup& g, int vec, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s);
+}  // namespace cgn_gemm

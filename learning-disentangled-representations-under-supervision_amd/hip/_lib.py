@@ -18,6 +18,8 @@ ATRANS_NONE = 0
 ATRANS_EXP = 1
 EPI_LINEAR = 0
 EPI_SOFTMAX_BWD = 1
+COMPUTE_F32 = 0
+COMPUTE_BF16 = 1
 
 c_float_p = C.c_void_p  # raw device pointers travel as integers
 c_i64 = C.c_int64
@@ -44,6 +46,7 @@ class GemmDesc(C.Structure):
         ("ep_inv_tau", c_f32), ("ep_ce_scale", c_f32),
         ("force_tile", c_i32), ("force_splitk", c_i32),
         ("dyn_scalars", c_ptr),
+        ("compute", c_i32), ("reserved0", c_i32),
     ]
 
 

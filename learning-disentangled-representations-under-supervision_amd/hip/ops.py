@@ -4,6 +4,7 @@ Every function validates device/dtype/shape on the host before a kernel is launc
 whole GPU node), launches on torch's current stream and returns torch tensors that alias caller-visible memory.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -12,6 +13,25 @@ from ._lib import Axis, GemmDesc
 
 _workspaces = {}
 WORKSPACE_BYTES = 96 << 20
+
+# Operand type of every MFMA product (cgn_gemm_desc.compute): "f32" (default, the parity mode) or "bf16" (north-star's
+# optional mode: operands rounded to bf16 inside the kernel, fp32 accumulation, fp32 everywhere else). Read when a
+# product is launched, so a captured hipGraph keeps the mode it was captured in.
+COMPUTE = _lib.COMPUTE_BF16 if os.environ.get("CGN_COMPUTE", "f32").lower() == "bf16" else _lib.COMPUTE_F32
+
+
+def set_compute(mode):
+    """'f32' | 'bf16'; returns the previous mode."""
+    global COMPUTE
+    if mode not in ("f32", "bf16"):
+        raise ValueError("compute mode must be 'f32' or 'bf16'")
+    prev = "bf16" if COMPUTE == _lib.COMPUTE_BF16 else "f32"
+    COMPUTE = _lib.COMPUTE_BF16 if mode == "bf16" else _lib.COMPUTE_F32
+    return prev
+
+
+def get_compute():
+    return "bf16" if COMPUTE == _lib.COMPUTE_BF16 else "f32"
 
 
 def _stream():
@@ -78,13 +98,14 @@ def _span_ok(t, base_off, axes_extents):
 
 def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, bias1=None,
          a_m=None, a_k=None, b_k=None, b_n=None, a_exp=None, softmax_bwd=None, force_tile=0, force_splitk=0,
-         dyn=None, _desc_only=False):
+         dyn=None, compute=None, _desc_only=False):
     """out[M,N] = epilogue(alpha * A @ B + beta*out + bias0 + bias1).
 
     `a` is viewed as A[M,K] and `b` as B[K,N]; arbitrary 2-D strides (so `w.t()` is free). The optional cgn Axis
     overrides give two-level addressing (see include/cgn_hip.h) for overlapping windows / history buffers; when an
     override is given, M/K/N must be given explicitly and `a`/`b` only provide the base pointer.
     a_exp=(scale, lse): A := exp(A*scale - lse[m]).   softmax_bwd=dict(logits, lse, rowdot, target, inv_tau, ce_scale).
+    compute: None (the module-level mode, see set_compute) | 'f32' | 'bf16'.
     """
     lib = _lib.load()
     _chk_f32(a, "a"), _chk_f32(b, "b"), _chk_f32(out, "out")
@@ -158,6 +179,7 @@ def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, 
     d.workspace_bytes = ws.numel() * 4
     d.force_tile, d.force_splitk = force_tile, force_splitk
     d.dyn_scalars = _ptr(dyn)
+    d.compute = COMPUTE if compute is None else (_lib.COMPUTE_BF16 if compute == "bf16" else _lib.COMPUTE_F32)
     if _desc_only:
         return d
     prof = GEMM_PROFILE

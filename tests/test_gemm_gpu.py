@@ -179,3 +179,89 @@ def test_gemm_group_matches_single_launches(dev, layouts):
     ops.gemm_group(calls)
     for out, ref in zip(outs, refs):
         assert torch.equal(out.cpu().double(), ref)
+
+
+# ---- optional bf16 operand mode (cgn_gemm_desc.compute = CGN_COMPUTE_BF16) ----------------------------------------
+def _bf(x):
+    return x.bfloat16().double()
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 300, 96), (1, 1, 1), (65, 129, 825), (257, 70, 365), (64, 64, 1024),
+                                   (33, 2048, 512)])
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt"])
+@pytest.mark.parametrize("tile", [0, 64, 128])
+def test_gemm_bf16_layouts(dev, M, N, K, layout, tile):
+    """bf16 operands, fp32 accumulation: equal to the fp64 product of the bf16-ROUNDED operands up to fp32 summation
+    error (<= 2e-6 relative), exact on small integers, and within north-star's 1e-2 of the unrounded product."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 131 + N * 17 + K + 1)
+    ints = (M + N + K) % 2 == 0
+    A = _mk((M, K), g, ints)
+    B = _mk((K, N), g, ints)
+    ref = _bf(A) @ _bf(B)
+    a = A.to(dev) if layout[0] == "n" else A.t().contiguous().to(dev).t()
+    b = B.to(dev) if layout[1] == "n" else B.t().contiguous().to(dev).t()
+    out = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(a, b, out, force_tile=tile, compute="bf16")
+    if ints:
+        assert torch.equal(out.cpu().double(), ref)
+    else:
+        assert _rel(out, ref) < 2e-6
+        assert _rel(out, A.double() @ B.double()) < 1e-2
+
+
+def test_gemm_bf16_splitk_windows_group_and_softmax(dev):
+    ops = _ops()
+    from ldrs_amd.hip._lib import Axis
+    g = torch.Generator().manual_seed(11)
+    # split-K + bias + beta
+    M, N, K = 150, 90, 1000
+    A, B = _mk((M, K), g), _mk((K, N), g)
+    C0, b0 = _mk((M, N), g), _mk((N,), g)
+    ref = 0.5 * (_bf(A) @ _bf(B)) + 2.0 * C0.double() + b0.double()
+    out = C0.to(dev).clone()
+    ops.gemm(A.to(dev), B.to(dev), out, alpha=0.5, beta=2.0, bias0=b0.to(dev), force_splitk=5, compute="bf16")
+    assert _rel(out, ref) < 2e-6
+    # overlapping conv windows (two-level A rows)
+    Bn, Lx, L, E, Kw, Co = 5, 9, 8, 12, 3, 7
+    x = _mk((Bn, Lx, E), g)
+    W = _mk((Co, 1, Kw, E), g)
+    refc = torch.nn.functional.conv2d(_bf(x[:, :L]).unsqueeze(1), _bf(W)).squeeze(3).permute(0, 2, 1)
+    refc = refc.reshape(Bn * (L - Kw + 1), Co)
+    outc = torch.empty(Bn * (L - Kw + 1), Co, device=dev)
+    ops.gemm(x.to(dev), W.to(dev).view(Co, Kw * E).t(), outc, M=Bn * (L - Kw + 1), K=Kw * E,
+             a_m=Axis(E, L - Kw + 1, Lx * E), a_k=Axis(1, 0, 0), compute="bf16")
+    assert _rel(outc, refc) < 2e-6
+    # grouped launch
+    calls, refs, outs = [], [], []
+    for i in range(3):
+        Mi, Ni, Ki = 70 + 33 * i, 40 + 28 * i, 24 + 36 * i
+        Ai, Bi = _mk((Mi, Ki), g), _mk((Ki, Ni), g)
+        o = torch.full((Mi, Ni), float("nan"), device=dev)
+        calls.append((Ai.to(dev), Bi.to(dev), o, dict(compute="bf16")))
+        refs.append(_bf(Ai) @ _bf(Bi))
+        outs.append(o)
+    ops.gemm_group(calls)
+    for o, r in zip(outs, refs):
+        assert _rel(o, r) < 2e-6
+    # softmax operand + fused softmax-backward epilogue against the UNROUNDED fp64 math: the 1e-2 bar of the bf16 mode
+    M, V, E = 70, 333, 24
+    tau = 0.9
+    logits = (_mk((M, V), g) * 3).double().requires_grad_(True)
+    emb = _mk((V, E), g).double()
+    target = torch.randint(0, V, (M,), generator=g)
+    dout = _mk((M, E), g).double()
+    ls = torch.log_softmax(logits / tau, dim=1)
+    soft = torch.exp(ls) @ emb
+    (torch.nn.functional.nll_loss(ls, target) * 79 + (soft * dout).sum()).backward()
+    lg, embd, tg = logits.detach().float().to(dev), emb.float().to(dev), target.to(dev)
+    lse, _, _ = ops.softmax_nll_fwd(lg, tg, 1.0 / tau)
+    out = torch.empty(M, E, device=dev)
+    ops.gemm(lg, embd, out, a_exp=(1.0 / tau, lse), compute="bf16")
+    assert _rel(out, soft.detach()) < 5e-3
+    dod = dout.float().to(dev)
+    rowdot = (dod * out).sum(1).contiguous()
+    dlogits = torch.empty(M, V, device=dev)
+    ops.gemm(dod, embd.t(), dlogits, compute="bf16",
+             softmax_bwd=dict(logits=lg, lse=lse, rowdot=rowdot, target=tg, inv_tau=1.0 / tau, ce_scale=79.0 / (M * tau)))
+    assert _rel(dlogits, logits.grad) < 1e-2

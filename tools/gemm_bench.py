@@ -40,7 +40,10 @@ cases = [eval(a) for a in sys.argv[1:]] or [
 ]
 from ldrs_amd.hip import _lib
 lib = _lib.load()
-for st in [int(x) for x in os.environ.get('GEMM_STAGES', '2').split(',')]:
+for mode in os.environ.get("GEMM_COMPUTE", "f32").split(","):
+  ops.set_compute(mode)
+  print("compute", mode)
+  for st in [int(x) for x in os.environ.get('GEMM_STAGES', '2').split(',')]:
     for order in [int(x) for x in os.environ.get('GEMM_ORDER', '2').split(',')]:
         lib.cgn_debug_set_stages(st | (order << 4))
         print("stages", st, "order", order)
