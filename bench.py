@@ -34,6 +34,7 @@ BATCH, SEQ = 64, 20
 CFG4 = dict(CFG2, max_seq_len=40, word_vocab_size=50000, encoder_rnn_size=1024, decoder_rnn_size=1024)
 WORKLOADS = {"cfg2": (CFG2, 64, 20), "cfg4": (CFG4, 256, 40)}
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 peak (~2.5 PF), --compute bf16 only
 
 
 def make_config(Config, cfgd=None):
@@ -87,6 +88,9 @@ def main():
     ap.add_argument("--eager", action="store_true", help="issue the step kernel by kernel instead of replaying a hipGraph")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2",
                     help="cfg2 = BASELINE configs[1] (the metric's workload); cfg4 = configs[3] shapes in fp32 (stress)")
+    ap.add_argument("--compute", choices=("f32", "bf16"), default="f32",
+                    help="MFMA operand type: f32 = the metric's parity mode; bf16 = north-star's optional mode (operands "
+                         "rounded to bf16 inside the GEMM kernels, fp32 accumulate/storage; tests/test_step_gpu.py bf16 case)")
     ap.add_argument("--force-dp", action="store_true",
                     help="single-GPU rehearsal of the data-parallel schedule: a one-rank RCCL group, collectives issued")
     args = ap.parse_args()
@@ -116,6 +120,7 @@ def main():
     ocfg = O.OracleConfig(**cfgd)
     if args.workload != "cfg2":
         args.no_cpu_baseline = True  # the CPU oracle needs minutes per step at this size
+    ops.set_compute(args.compute)
     torch.manual_seed(1234)  # identical replicas on every rank
     model = Controlled_Generation_Sentence(cfg, O.synthetic_word_embed(ocfg)).cuda()
     if world > 1 or args.force_dp:
@@ -197,7 +202,7 @@ def main():
         # WRITE_SIZE in separate runs, FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes)
         traffic, traffic_src = None, None
         tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tp) and args.workload == "cfg2":
+        if os.path.exists(tp) and args.workload == "cfg2" and args.compute == "f32":
             with open(tp) as f:
                 tj = json.load(f)
             for k, v in tj["kernels"].items():
@@ -210,25 +215,30 @@ def main():
         ms = sum(e0.elapsed_time(e1) for *_, e0, e1 in recs)
         launches = len(recs)
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        peak = FP32_MFMA_PEAK_TFLOPS if args.compute == "f32" else BF16_MFMA_PEAK_TFLOPS
         out = {
             "metric": "wake-sleep training sentences/sec", "value": world * BATCH * args.steps / elapsed,
             "unit": "sentences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.compute, "data": "synthetic",
             "config": {"workload": "CGN full wake-sleep training step (disc step + c inference + enc/gen step + 3 Adam), "
                                    + ("BASELINE configs[1]: vocab 20k, seq len 20, batch 64/GPU, emb 300, hidden 512, "
                                       "z 64, " if args.workload == "cfg2" else
                                       "BASELINE configs[3] SHAPES in fp32 (stress, not the metric's workload): vocab 50k, "
                                       "seq len 40, batch 256/GPU, hidden 1024, z 64, ")
-                                   + "fp32, calc_z_loss=%s" % args.z_loss,
+                                   + ("fp32" if args.compute == "f32" else "OPTIONAL bf16 mode (bf16 MFMA operands, fp32 "
+                                      "accumulation and storage; not the metric's fp32 configuration)")
+                                   + ", calc_z_loss=%s" % args.z_loss,
                        "global_batch": world * BATCH, "seq_len": SEQ, "parallelism": "dp%d" % world,
                        "launch": ("hipGraph replay" if world == 1 and not args.force_dp else
                                   "hipGraph segments + eager RCCL all-reduce") if use_graph else "eager"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
                          "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
-                         "kernel": "gemm_kernel<128,true,true,3,false,2,16,false> (NT fp32 MFMA GEMM, 128x128 tile, "
-                                   "linear epilogue: the vocabulary projection h1 @ fc.weight^T + bias -> logits)",
+                         "kernel": ("gemm_kernel<128,true,true,3,false,2,16,false> (NT fp32 MFMA GEMM, 128x128 tile, "
+                                    if args.compute == "f32" else
+                                    "gemm_kernel<128,true,true,3,false,2,32,false,true> (NT bf16-operand MFMA GEMM, 128x128 "
+                                    "tile, ") + "linear epilogue: the vocabulary projection h1 @ fc.weight^T + bias -> logits)",
                          "launches_per_step": 1.0,
                          "avg_launch_us": 1e3 * ms / max(launches, 1),
                          "algorithmic_gflop_per_launch": flops / max(launches, 1) / 1e9,

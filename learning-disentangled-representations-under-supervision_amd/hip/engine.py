@@ -56,8 +56,10 @@ def tdnn_conv_fwd(xw, N, Wl, kernels):
         P = Wl - kW + 1
         conv = _new((N * P, od), dev)
         # row (n,p) = xw[n, p:p+kW, :] (contiguous kW*Cc floats, order (j,c)); weight element (o, c, j) -> k = j*Cc + c
+        # compute="f32" also in the bf16 mode: these products feed a max-over-time selection, whose argmax would flip
+        # under bf16 operand rounding (0.3 % of the step's FLOPs)
         calls.append((xw, k, conv, dict(M=N * P, N=od, K=kW * Cc, a_m=Axis(Cc, P, Wl * Cc), a_k=LIN,
-                                        b_k=Axis(kW, Cc, 1), b_n=Axis(Cc * kW, 0, 0))))
+                                        b_k=Axis(kW, Cc, 1), b_n=Axis(Cc * kW, 0, 0), compute="f32")))
         convs.append(conv), Ps.append(P), cols.append(col)
         col += od
     # all widths in one grouped GEMM launch + one pooling launch (the reference loops over F.conv1d, tdnn.py:41-44)
@@ -112,12 +114,16 @@ def highway_fwd(x, layers):
     saved = []
     for p in layers:
         pre = _new((N, 3 * Sp), x.device)
+        # compute="f32" also in the bf16 mode: the nonlinear branch feeds a ReLU whose gates flip under bf16 operand
+        # rounding, and the gradients below the highway (char-TDNN, char embedding) amplify the perturbation of the
+        # other two branches: measured against the oracle (tools/bf16_sensitivity.py, tests/test_step_gpu.py) they go
+        # 3e-2 with all three branches in bf16, 1.6e-2 with the ReLU branch alone in fp32, 6e-3 with all three in fp32
         if p.get("wcat") is not None:
-            ops.gemm(x, p["wcat"].t(), pre, bias0=p["bcat"])
+            ops.gemm(x, p["wcat"].t(), pre, bias0=p["bcat"], compute="f32")
         else:
-            ops.gemm(x, p["nw"].t(), pre[:, 0:S], bias0=p["nb"])
-            ops.gemm(x, p["lw"].t(), pre[:, Sp:Sp + S], bias0=p["lb"])
-            ops.gemm(x, p["gw"].t(), pre[:, 2 * Sp:2 * Sp + S], bias0=p["gb"])
+            ops.gemm(x, p["nw"].t(), pre[:, 0:S], bias0=p["nb"], compute="f32")
+            ops.gemm(x, p["lw"].t(), pre[:, Sp:Sp + S], bias0=p["lb"], compute="f32")
+            ops.gemm(x, p["gw"].t(), pre[:, 2 * Sp:2 * Sp + S], bias0=p["gb"], compute="f32")
         y = ops.new2d(N, S, x.device)
         ops.highway_gate_fwd(pre, S, y)
         saved.append((x, pre))
@@ -276,8 +282,9 @@ def textcnn_features_fwd(x, B, L, E, sent_stride, conv_w, conv_b, grouped=True):
             raise RuntimeError("Kernel size can't be greater than actual input size (K=%d, L=%d)" % (K, L))
         P = L - K + 1
         conv = _new((B * P, Co), dev)
+        # fp32 products in both compute modes: ReLU + max-over-time selections follow (see tdnn_conv_fwd)
         calls.append((x, w.view(Co, K * E).t(), conv, dict(M=B * P, K=K * E, a_m=Axis(E, P, sent_stride), a_k=LIN,
-                                                            bias0=b)))
+                                                            bias0=b, compute="f32")))
         convs.append(conv), Ps.append(P), cols.append(col)
         col += Co
     if grouped:

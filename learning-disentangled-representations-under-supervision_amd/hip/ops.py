@@ -738,7 +738,7 @@ def conv_bwd_dx_dense(Ks, Cos, act, layout, W, dfeat, feat, arg, B, L, E, dx, se
             kw = dict(M=B * P, N=K * E, K=Co, b_k=Axis(K * E, 0, 0), b_n=Axis(1, 0, 0))
         else:  # element (o, c, j) of [Co, E, K] -> column n = j*E + c
             kw = dict(M=B * P, N=K * E, K=Co, b_k=Axis(K * E, 0, 0), b_n=Axis(K, E, 1))
-        kw.update(a_m=Axis(Co, 0, 0), a_k=Axis(1, 0, 0))
+        kw.update(a_m=Axis(Co, 0, 0), a_k=Axis(1, 0, 0), compute="f32")  # convolutions stay fp32 in the bf16 mode
         calls.append((dc, W[i], dl, kw))
         dconvs.append(dc), dcols.append(dl)
     ptrs = (C.c_void_p * n)(*[t_.data_ptr() for t_ in dconvs])
