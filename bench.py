@@ -206,7 +206,7 @@ def main():
             with open(tp) as f:
                 tj = json.load(f)
             for k, v in tj["kernels"].items():
-                if k.startswith("gemm_kernel<128, true, true, 3, false, 2, 16, false>") and k.endswith("g1727"):
+                if k.startswith("gemm_kernel<128, true, true, 3, false, 2, 16, false, false>") and k.endswith("g1727"):
                     traffic, traffic_src = v["traffic"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, %d launches)" % v["launches"]
         # the roofline kernel is ONE symbol: the linear-epilogue NT 128-tile variant = the vocabulary projection (the
         # dlogits product shares the tile shape but runs the softmax-backward epilogue variant, a different symbol)
@@ -224,7 +224,7 @@ def main():
             "config": {"workload": "CGN full wake-sleep training step (disc step + c inference + enc/gen step + 3 Adam), "
                                    + ("BASELINE configs[1]: vocab 20k, seq len 20, batch 64/GPU, emb 300, hidden 512, "
                                       "z 64, " if args.workload == "cfg2" else
-                                      "BASELINE configs[3] SHAPES in fp32 (stress, not the metric's workload): vocab 50k, "
+                                      "BASELINE configs[3] SHAPES (stress, not the metric's workload; fp32 tensors): vocab 50k, "
                                       "seq len 40, batch 256/GPU, hidden 1024, z 64, ")
                                    + ("fp32" if args.compute == "f32" else "OPTIONAL bf16 mode (bf16 MFMA operands, fp32 "
                                       "accumulation and storage; not the metric's fp32 configuration)")
@@ -235,9 +235,9 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
-                         "kernel": ("gemm_kernel<128,true,true,3,false,2,16,false> (NT fp32 MFMA GEMM, 128x128 tile, "
+                         "kernel": ("cgn_gemm::gemm_kernel<128,true,true,3,false,2,16,false,false> (NT fp32 MFMA GEMM, 128x128 tile, "
                                     if args.compute == "f32" else
-                                    "gemm_kernel<128,true,true,3,false,2,32,false,true> (NT bf16-operand MFMA GEMM, 128x128 "
+                                    "cgn_gemm::gemm_kernel<128,true,true,3,false,2,32,false,true> (NT bf16-operand MFMA GEMM, 128x128 "
                                     "tile, ") + "linear epilogue: the vocabulary projection h1 @ fc.weight^T + bias -> logits)",
                          "launches_per_step": 1.0,
                          "avg_launch_us": 1e3 * ms / max(launches, 1),

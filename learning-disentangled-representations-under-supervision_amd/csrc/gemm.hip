@@ -1,17 +1,6 @@
-// fp32 MFMA GEMM for gfx950: C = epilogue(alpha * A·B + beta*C + bias), exact-fp32 v_mfma_f32_32x32x2_f32.
-//
-// Design (MI355X_MICROARCH: the f32 MFMA runs at the f32 vector rate, 64 cycles per 32x32x2 per SIMD, so the loop
-// is MFMA-paced and LDS/global staging only has to stay out of the way):
-//   * square block tile BT x BT (128 or 64), BK = 32, 256 threads = 4 waves in a 2x2 grid, each wave owns
-//     (BT/2)x(BT/2) outputs as (BT/64)^2 accumulators of 32x32;
-//   * operands are staged global -> registers -> LDS in a k-major [BK][BT+1] image: the MFMA fragment read
-//     (lane l: row l&31 of k-slice l>>5) is then 32 consecutive floats per half-wave = bank-conflict free;
-//   * the next K tile's global loads are issued before the current tile's MFMAs (register prefetch);
-//   * two-level addressing on every operand axis (see cgn_hip.h) covers transposed operands, overlapping conv
-//     windows and [B,T+1,H] history buffers without copies;
-//   * tall-K / few-tile problems are split along K into fp32 slabs, summed in fixed order by a second kernel
-//     (bitwise reproducible, no float atomics);
-//   * blockIdx -> tile mapping is XCD-aware: blocks that share an XCD (blockIdx % 8) walk neighbouring tiles.
+// MFMA GEMM for gfx950, host side: C = epilogue(alpha * A·B + beta*C + bias). Descriptor validation, the tile / split-K
+// plan and the entry points cgn_gemm_f32 / cgn_gemm_group_f32 / cgn_gemm_plan. The device templates are in gemm_core.h;
+// this file instantiates them for exact-fp32 operands (v_mfma_f32_32x32x2_f32), gemm_bf16.hip for bf16 operands.
 #include "gemm_core.h"
 
 using namespace cgn_gemm;

@@ -1,4 +1,18 @@
-// Device templates of the MFMA GEMM (included by gemm.hip: fp32 operands, and gemm_bf16.hip: bf16 operands).
+// Device templates of the MFMA GEMM for gfx950 (included by gemm.hip: fp32 operands on v_mfma_f32_32x32x2_f32, and by
+// gemm_bf16.hip: operands rounded to bf16 at LDS staging, v_mfma_f32_32x32x16_bf16, fp32 accumulation).
+//
+// Design (MI355X_MICROARCH: the f32 MFMA runs at the f32 vector rate, 64 cycles per 32x32x2 per SIMD, so the fp32 loop
+// is MFMA-paced and LDS/global staging only has to stay out of the way; the bf16 loop is paced by operand traffic):
+//   * square block tile BT x BT (128 or 64), 256 threads = 4 waves in a 2x2 grid, each wave owns (BT/2)x(BT/2) outputs
+//     as (BT/64)^2 accumulators of 32x32; BK = 16 / 32 (fp32, by tile) or 32 / 64 (bf16);
+//   * operands are staged global -> registers -> LDS in a row-major [BT][BK + 16 bytes] image of each operand: a
+//     lane's MFMA fragment (4 fp32 or 8 bf16 consecutive k of its row) is one conflict-free ds_read_b128;
+//   * S register stages of global loads are in flight under the MFMAs; loads are unconditional on clamped addresses;
+//   * two-level addressing on every operand axis (see cgn_hip.h) covers transposed operands, overlapping conv
+//     windows and [B,T+1,H] history buffers without copies;
+//   * tall-K / few-tile problems are split along K into fp32 slabs, summed in fixed order by a second kernel
+//     (bitwise reproducible, no float atomics);
+//   * blockIdx -> tile mapping is XCD-aware: blocks that share an XCD (blockIdx % 8) walk neighbouring tiles.
 #pragma once
 #include "common.h"
 
@@ -59,7 +73,7 @@ struct GemmParams {
 };
 
 constexpr int g_unroll_mult = 2;
-constexpr int KROUND = 32;  // split-K ranges are multiples of every BK in use
+constexpr int KROUND = 32;  // split-K ranges start on multiples of 32 (aligned k quads; the fp32 BKs divide it)
 constexpr int NT = 256;
 
 __device__ __forceinline__ float apply_epilogue(const GemmParams& p, int row, int col, float acc) {
