@@ -71,7 +71,7 @@ typedef struct cgn_gemm_desc {
     const float* ep_lse;
     const float* ep_rowdot;
     const int64_t* ep_target;
-    float* workspace; /* split-K slabs; may be NULL (then no split-K) */
+    float* workspace; /* split-K slabs, 16-byte aligned: splitk * M * ceil4(N) floats are used; may be NULL (no split-K) */
     int64_t workspace_bytes;
     int64_t ldc;
     int64_t ep_ld;

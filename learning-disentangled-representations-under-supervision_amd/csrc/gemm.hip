@@ -83,10 +83,11 @@ int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out
         splitk = (int)want;
     }
     if (splitk > 1) {
-        const long need = (long)splitk * d->M * d->N * (long)sizeof(float);
+        const long ldw = (d->N + 3) / 4 * 4;  // slab rows are padded to whole quads
+        const long need = (long)splitk * d->M * ldw * (long)sizeof(float);
         if (!d->workspace || d->workspace_bytes < need) {
             if (d->force_splitk > 0) return CGN_ERR_WORKSPACE;
-            const long fit = d->workspace ? d->workspace_bytes / ((long)d->M * d->N * (long)sizeof(float)) : 0;
+            const long fit = d->workspace ? d->workspace_bytes / ((long)d->M * ldw * (long)sizeof(float)) : 0;
             splitk = fit >= 2 ? (int)fit : 1;
         }
     }
@@ -158,6 +159,7 @@ static int prepare_gemm(const cgn_gemm_desc* d, GemmParams& p, bool& a_kc, bool&
               (a_kc ? axis_vec_ok(d->a_k, d->a_m, d->K) : axis_vec_ok(d->a_m, d->a_k, d->M));
     p.b_vec = ((uintptr_t)d->B % 16 == 0) &&
               (b_kc ? axis_vec_ok(d->b_k, d->b_n, d->K) : axis_vec_ok(d->b_n, d->b_k, d->N));
+    CGN_CHECK_ARG((uintptr_t)d->workspace % 16 == 0);
     p.ws = d->workspace;
     p.dyn = d->dyn_scalars;
     p.order = g_order;
@@ -182,6 +184,7 @@ extern "C" int cgn_gemm_f32(void* stream, const cgn_gemm_desc* d) {
     const long tiles = (long)p.tiles_m * p.tiles_n;
     p.k_per_split = kps;
     p.splitk = splitk;
+    p.ldw = (d->N + 3) / 4 * 4;
 
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)tiles, (unsigned)splitk);
@@ -191,15 +194,10 @@ extern "C" int cgn_gemm_f32(void* stream, const cgn_gemm_desc* d) {
         launch_gemm_f32ops(p, bt, a_kc, b_kc, grid, s);
     CGN_LAUNCH_CHECK();
     if (splitk > 1) {
-        const long total = (long)d->M * d->N;
-        const bool vec = d->N % 4 == 0;  // slabs are dense [M, N] at a 256-byte aligned base: rows of 4k columns align
-        int blocks = cgn_cdiv(total / (vec ? 4 : 1), 256);
+        int blocks = cgn_cdiv((long)d->M * p.ldw / 4, 256);
         if (blocks > 2048) blocks = 2048;
         if (blocks < 1) blocks = 1;
-        if (vec)
-            hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, s, p);
-        else
-            hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
         CGN_LAUNCH_CHECK();
     }
     return CGN_OK;

@@ -62,6 +62,7 @@ struct GemmParams {
     float* ws;
     const float* dyn;  // optional device scalars {inv_tau, ce_scale}: override a_scale/ep_inv_tau and ep_ce_scale
     long ldc, ep_ld;
+    long ldw;  // row stride of the split-K slabs: N rounded up to 4, so the reduce always reads 16-byte quads
     Axis am, ak, bk, bn;
     int M, N, K;
     int k_per_split, splitk;
@@ -517,7 +518,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
                 const int row = m0 + wm * (BT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
                 if (row >= p.M) continue;
                 if (p.splitk > 1) {
-                    p.ws[((long)split * p.M + row) * p.N + col] = acc[0][i][j][r];
+                    p.ws[((long)split * p.M + row) * p.ldw + col] = acc[0][i][j][r];
                 } else {
                     p.C[(long)row * p.ldc + col] = apply_epilogue(p, row, col, acc[0][i][j][r]);
                 }
@@ -566,44 +567,35 @@ __global__ __launch_bounds__(NT, 2) void gemm_group_kernel(const GemmGroup g) {
     gemm_tile<BT, A_KC, B_KC, VEC, false, S, BK, false, BF>(g.p[j], 0, t);
 }
 
-// Sums the split-K slabs in fixed order z = 0..splitk-1 (bitwise reproducible). VEC: four consecutive columns per
-// thread (16-byte slab loads, N % 4 == 0). The slab loads of 4 splits are issued together before they are added: with
-// one load per trip the kernel was a chain of L2 round trips (12.7 us for 16 MB of slabs).
-template <bool VEC>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
-    constexpr int W = VEC ? 4 : 1;
-    const long total = (long)p.M * p.N;
-    const long nvec = total / W;
+// Sums the split-K slabs in fixed order z = 0..splitk-1 (bitwise reproducible). Slab rows are ldw = ceil4(N) floats
+// apart, so every thread reads 16-byte quads whatever N is (N = 825 made the scalar form the common one: 13 us against
+// 6 us per launch). The slab loads of 4 splits are issued together before they are added: with one load per trip the
+// kernel was a chain of L2 round trips (12.7 us for 16 MB of slabs).
+static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
+    const long total = (long)p.M * p.ldw;
+    const long nvec = total / 4;
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
-        const long idx = v * W;
-        float s[W];
-#pragma unroll
-        for (int j = 0; j < W; ++j) s[j] = 0.f;
+        const long idx = v * 4;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
         for (int z0 = 0; z0 < p.splitk; z0 += 4) {
-            float part[4][W];
+            f32x4 part[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int z = min(z0 + u, p.splitk - 1);
-                const float* src = p.ws + (long)z * total + idx;
-                if constexpr (VEC) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(src);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) part[u][j] = t[j];
-                } else {
-                    part[u][0] = *src;
-                }
+                part[u] = *reinterpret_cast<const f32x4*>(p.ws + (long)z * total + idx);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (z0 + u < p.splitk) {
 #pragma unroll
-                    for (int j = 0; j < W; ++j) s[j] += part[u][j];
+                    for (int j = 0; j < 4; ++j) s[j] += part[u][j];
                 }
             }
         }
-        const int row = (int)(idx / p.N), col = (int)(idx % p.N);
+        const int row = (int)(idx / p.ldw), col = (int)(idx % p.ldw);
 #pragma unroll
-        for (int j = 0; j < W; ++j) p.C[(long)row * p.ldc + col + j] = apply_epilogue(p, row, col + j, s[j]);
+        for (int j = 0; j < 4; ++j)
+            if (col + j < p.N) p.C[(long)row * p.ldc + col + j] = apply_epilogue(p, row, col + j, s[j]);
     }
 }
 
