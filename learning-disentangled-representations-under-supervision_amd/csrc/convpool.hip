@@ -239,17 +239,19 @@ __global__ __launch_bounds__(256) void conv_bwd_dx_kernel(const ConvWidths w, co
 }
 
 // dW[map][window element] (+)= sum_b g[b,map] * x[b, t0(b,map) + k, e];  db[map] (+)= sum_b g[b,map].
-// Workgroup = 64 window elements of one map; its 4 waves split the batch four ways and are summed through LDS in
-// fixed order. (t0, g) of 64 sentences are loaded one per lane and broadcast; the x loads of DWU sentences are issued
+// Workgroup = 64 window elements of one map; its NW waves split the batch NW ways and are summed through LDS in
+// fixed order (NW = 16 for long batches: the char-TDNN's "batch" is every word of the step, and with 4 waves each
+// walked 320 words in 20 dependent rounds of loads: 69 us). (t0, g) of 64 sentences are loaded one per lane and broadcast; the x loads of DWU sentences are issued
 // together (independent addresses) before any is consumed, so the walk over the batch is not one L2 round trip per
 // sentence.
 constexpr int DWU = 16;
-__global__ __launch_bounds__(256) void conv_bwd_dw_kernel(const ConvWidths w, const float* __restrict__ dfeat,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void conv_bwd_dw_kernel(const ConvWidths w, const float* __restrict__ dfeat,
                                                           const float* __restrict__ feat, const int32_t* __restrict__ arg,
                                                           const float* __restrict__ x, long sent_stride, int B, int L,
                                                           int E, float beta) {
-    __shared__ float red[4][64];
-    __shared__ float redb[4];
+    __shared__ float red[NW][64];
+    __shared__ float redb[NW];
     const int wi = blockIdx.z, co = blockIdx.y;
     const int Kw = w.K[wi];
     const int KE = Kw * E;
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256) void conv_bwd_dw_kernel(const ConvWidths w, co
     const int i = blockIdx.x * 64 + lane;  // window element, order (k, e)
     const bool live = i < KE;
     const int il = live ? i : 0;
-    const int per = (B + 3) / 4;
+    const int per = (B + NW - 1) / NW;
     const int b_beg = wave * per, b_end = min(B, b_beg + per);
     float acc = 0.f, bsum = 0.f;
     for (int bb = b_beg; bb < b_end; bb += 64) {
@@ -294,14 +296,18 @@ __global__ __launch_bounds__(256) void conv_bwd_dw_kernel(const ConvWidths w, co
     if (lane == 0) redb[wave] = bsum;
     __syncthreads();
     if (wave == 0) {
-        const float tot = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        float tot = 0.f;
+#pragma unroll
+        for (int v = 0; v < NW; ++v) tot += red[v][lane];
         if (live) {
             const int di = (w.layout == 0) ? i : (i % E) * Kw + (i / E);
             float* d = w.dW[wi] + (long)co * KE + di;
             *d = (beta != 0.f) ? tot + beta * (*d) : tot;
         }
         if (blockIdx.x == 0 && lane == 0 && w.db[wi]) {
-            const float bs = redb[0] + redb[1] + redb[2] + redb[3];
+            float bs = 0.f;
+#pragma unroll
+            for (int v = 0; v < NW; ++v) bs += redb[v];
             float* d = w.db[wi] + co;
             *d = (beta != 0.f) ? bs + beta * (*d) : bs;
         }
@@ -480,8 +486,12 @@ extern "C" int cgn_conv_bwd_dw_f32(void* stream, const cgn_conv_widths* widths, 
     }
     CGN_CHECK_ARG(maxco <= 65535);
     dim3 grid(cgn_cdiv(maxke, 64), maxco, cw.n);
-    hipLaunchKernelGGL(conv_bwd_dw_kernel, grid, dim3(256), 0, (hipStream_t)stream, cw, dfeat, feat, arg, x,
-                       (long)sent_stride, B, L, E, beta);
+    if (B >= 512)
+        hipLaunchKernelGGL(conv_bwd_dw_kernel<16>, grid, dim3(1024), 0, (hipStream_t)stream, cw, dfeat, feat, arg, x,
+                           (long)sent_stride, B, L, E, beta);
+    else
+        hipLaunchKernelGGL(conv_bwd_dw_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, cw, dfeat, feat, arg, x,
+                           (long)sent_stride, B, L, E, beta);
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }
