@@ -11,11 +11,16 @@ Every function cites the reference file:line it follows. Differences from the re
   * hyper-parameters are parametric (OracleConfig) with the reference's values as defaults.
 
 Pinning: the reference has no tests, golden vectors or fixtures. This oracle is pinned by
-outputs of the reference's own modules run in the build container (tests/golden/make_golden.py imports
-Generator, Highway, Encoder, Sentiment_CNN, kld_coef/temp_coef from /root/reference and stores inputs, weights and
-outputs in tests/golden/*.npz); tests/test_oracle_golden.py checks this file against those vectors. The step
-closures (cgn.py:269-341, :1049-1154) cannot run under torch 2.x even after 2to3 (removed API) and are therefore
-restated line by line here: for those two functions parity is pinned by the module-level vectors only.
+outputs of the reference's own code run in the build container and committed as data under tests/golden/:
+  * module level (tests/golden/make_golden.py -> reference_modules.npz, checked by tests/test_oracle_golden.py):
+    Generator, Highway, Encoder, Sentiment_CNN forward outputs, kld_coef / temp_coef, Config facts;
+  * STEP level (tests/golden/make_golden_step.py -> reference_step.npz, checked by tests/test_oracle_step_golden.py):
+    the reference's own closures - discriminator_sentiment_trainer().train (cgn.py:269-341), discriminator_forward
+    (:134-172) and train_encoder_generator().train (:1049-1154) - executed for two consecutive wake-sleep iterations
+    (Python-2 files converted in memory with lib2to3; two textual substitutions for renamed / removed torch spellings,
+    listed in that script). Every loss, every gradient the closures leave in .grad (incl. the z.grad alias routing)
+    and every parameter after Adam agree with this file to fp32 rounding (most of them bit for bit).
+The multi-attribute extension (c_size > 1) has no counterpart in the reference: parity unpinned for it.
 """
 import math
 

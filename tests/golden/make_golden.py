@@ -8,7 +8,7 @@ selfModules/highway.py Highway.forward, model/encoder.py Encoder.forward, utils/
 utils/config.py Config, and model/discriminator_sentiment.py Sentiment_CNN.forward — that file is Python-2 syntax
 (print statements), so it is converted IN MEMORY with lib2to3 and exec'd; nothing is written to disk.
 selfModules/tdnn.py TDNN.forward does not run under torch 2.x (keepdim-era squeeze, tdnn.py:43) and cgn.py's step
-closures use removed torch API: those stay pinned by the oracle restatement only.
+closures are run by tests/golden/make_golden_step.py (two textual substitutions, listed there).
 
 The .npz holds only data: seeds-derived inputs, the modules' state_dicts and their outputs.
 """

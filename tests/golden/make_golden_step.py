@@ -1,0 +1,201 @@
+"""Generates tests/golden/reference_step.npz by RUNNING the reference's own step closures (build container only):
+model/cgn.py  discriminator_sentiment_trainer().train (:269-341), discriminator_forward (:134-172) and
+train_encoder_generator().train (:1049-1154), in the order train_functions.py:24-90 calls them, on the CPU, for two
+consecutive wake-sleep iterations (the second one exercises Adam's moments and the updated weights).
+
+Run as:  python -O tests/golden/make_golden_step.py      (-O: model/encoder.py:35 asserts on a helper that is not
+torch-2.x clean, utils/functional.py:13-15)
+
+How the Python-2 / old-torch sources are made to run under Python 3.10 / torch 2.10 — all IN MEMORY, nothing from the
+reference is written to disk or into this repository:
+  * model/cgn.py, model/discriminator_sentiment.py, selfModules/embedding.py hold Python-2 print statements: converted
+    with lib2to3 and exec'd as modules of their own packages;
+  * TWO textual substitutions, each the documented modern spelling of the same operation:
+      - selfModules/tdnn.py:43   `x.max(2)[0].squeeze(2)` -> `x.max(2)[0]`   (torch < 0.2 kept the reduced dimension;
+        the squeeze only removed it again; torch >= 0.2 reductions drop it themselves and the squeeze then raises);
+      - model/cgn.py:1097,1147   `backward(retain_variables=True)` -> `backward(retain_graph=True)`  (argument renamed
+        in torch 0.2, old name removed later);
+  * model/encoder.py, model/generator.py, selfModules/highway.py, utils/functional.py, utils/config.py, utils/beam_search.py
+    are imported as they are.
+Everything else is the reference's code executing: the optimizers it builds, its gradient routing (the z.grad alias,
+generator step before the encoder backward), its losses. Schedules are evaluated under Python-3 division
+(kld_coef: true division, i.e. the oracle's py2_floor=False). Generator dropout is 0.0 (F.dropout's default
+`training` flag changed between torch versions; with p = 0 it is the identity under every version).
+
+Random draws are recovered, not re-implemented: eps of encode_for_z (:96) by re-seeding torch's generator with the seed
+set right before the call (nothing else draws in between: the text-CNN is in eval mode, every dropout has p = 0); the
+text-CNN's training-mode dropout masks of the discriminator step with a forward hook on its nn.Dropout; the Bernoulli
+draw of c (:170) is recorded as drawn, together with the probabilities it was drawn from.
+
+The .npz holds only data: config dims, the initial state_dict, the batches, the recovered draws and the outputs
+(losses, c, per-parameter gradients left in .grad by the closures, parameters after each iteration).
+"""
+import contextlib
+import io
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_step.npz")
+
+
+def exec_module(relpath, modname, package, subs=(), py2=True):
+    src = open(os.path.join(REF, relpath)).read()
+    for old, new in subs:
+        assert src.count(old) >= 1, (relpath, old)
+        src = src.replace(old, new)
+    if py2:
+        from lib2to3 import refactor
+        tool = refactor.RefactoringTool(refactor.get_fixers_from_package("lib2to3.fixes"))
+        src = str(tool.refactor_string(src + "\n", relpath))
+    mod = types.ModuleType(modname)
+    mod.__package__ = package
+    mod.__file__ = relpath + " (in memory)"
+    sys.modules[modname] = mod
+    exec(compile(src, relpath + "(in memory)", "exec"), mod.__dict__)
+    return mod
+
+
+class Handler:
+    """The two data_handler calls the discriminator closure makes (cgn.py:276, 282-283)."""
+
+    def __init__(self):
+        self.X = self.Y = None
+
+    def get_sentiment_train_batch(self, i):
+        return self.X, self.Y
+
+    def create_sentiment_batch(self, sentences):
+        return torch.tensor(sentences, dtype=torch.int64)
+
+
+def main():
+    if __debug__:
+        raise SystemExit("run with python -O (see module docstring)")
+    sys.path.insert(0, REF)
+    import model  # noqa: F401  the reference's packages (their __init__ files are empty)
+    import selfModules  # noqa: F401
+    from utils.config import Config
+
+    exec_module("selfModules/tdnn.py", "selfModules.tdnn", "selfModules",
+                subs=[("x.max(2)[0].squeeze(2)", "x.max(2)[0]")], py2=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        exec_module("selfModules/embedding.py", "selfModules.embedding", "selfModules")
+        exec_module("model/discriminator_sentiment.py", "model.discriminator_sentiment", "model")
+        cgn_mod = exec_module("model/cgn.py", "model.cgn", "model",
+                              subs=[("backward(retain_variables=True)", "backward(retain_graph=True)")])
+
+    cfg = Config(max_word_len=7, max_seq_len=5, word_vocab_size=50, char_vocab_size=20, learning_rate=5e-5,
+                 lambda_c=7.9, lambda_z=0.1, lambda_u=0.1, beta=1.0)
+    # shrink the hard-coded dims (config.py:14-31) so the fixture stays small
+    cfg.word_embed_size, cfg.encoder_rnn_size, cfg.latent_variable_size = 12, 16, 6
+    cfg.decoder_rnn_size, cfg.decoder_num_layers = 20, 2
+    cfg.kernels = [(1, 3), (2, 5), (3, 4)]
+    cfg.sum_depth = 12
+    cfg.sentiment_kernel_size, cfg.sentiment_kernel_num = [3, 4, 5], 6
+    out = {"dims": np.array([cfg.max_word_len, cfg.max_seq_len, cfg.word_vocab_size, cfg.char_vocab_size,
+                             cfg.word_embed_size, cfg.encoder_rnn_size, cfg.latent_variable_size, cfg.decoder_rnn_size,
+                             cfg.sentiment_kernel_num, cfg.char_embed_size]),
+           "sentiment_dropout": np.array(cfg.sentiment_dropout), "learning_rate": np.array(cfg.learning_rate)}
+
+    g = torch.Generator().manual_seed(20171110)
+    V, E = cfg.word_vocab_size, cfg.word_embed_size
+    word_embed = ((torch.rand(V, E, generator=g) * 2 - 1) * 0.25).numpy()
+    out["word_embed"] = word_embed
+    torch.manual_seed(1)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "word_embeddings.npy")
+        np.save(path, word_embed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            cgn = cgn_mod.Controlled_Generation_Sentence(cfg, path)
+    for k, v in cgn.state_dict().items():
+        out["init/" + k] = v.detach().numpy().copy()
+
+    handler = Handler()
+    # train_functions.py:24-33
+    cgn.discriminator_mode(train_mode=True)
+    cgn.encoder_mode(train_mode=True)
+    cgn.generator_mode(train_mode=True)
+    disc_step = cgn.discriminator_sentiment_trainer(handler, False)
+    enc_gen_step = cgn.train_encoder_generator(None)
+
+    masks = []
+    hook = cgn.sentiment_discriminator.dropout.register_forward_hook(
+        lambda m, i, o: masks.append((i[0].detach().clone(), o.detach().clone())) if m.training else None)
+    p_keep = 1.0 - cfg.sentiment_dropout
+
+    B, L = 4, cfg.max_seq_len - 1
+    for it in range(2):
+        tag = "it%d/" % it
+        calc_z = it == 1  # iteration 0 as train_functions.py runs it (calc_z_loss=False), iteration 1 with the z pass
+        s = torch.randint(0, V - 3, (B, L), generator=g)
+        chars = torch.randint(0, cfg.char_vocab_size, (B, L, cfg.max_word_len), generator=g)
+        go, end = V - 2, V - 1
+        batch = [torch.flip(s, dims=[1]).contiguous().numpy(), torch.flip(chars, dims=[1]).contiguous().numpy(),
+                 torch.cat([torch.full((B, 1), go, dtype=torch.int64), s], 1).numpy(),
+                 np.zeros((B, L + 1, cfg.max_word_len), np.int64),  # decoder character input: converted, never used (:1058)
+                 torch.cat([s, torch.full((B, 1), end, dtype=torch.int64)], 1).numpy()]
+        x_lab = torch.randint(0, V - 3, (B, L), generator=g)
+        y_lab = torch.randint(0, 2, (B,), generator=g)
+        x_gen = torch.randint(0, V - 3, (B, L), generator=g)
+        c_gen = torch.randint(0, 2, (B,), generator=g).float().view(B, 1)
+        for nm, a in (("enc_word", batch[0]), ("enc_char", batch[1]), ("dec_word", batch[2]), ("target", batch[4]),
+                      ("x_labelled", x_lab.numpy()), ("y_labelled", y_lab.numpy()), ("x_generated", x_gen.numpy()),
+                      ("c_generated", c_gen.numpy())):
+            out[tag + nm] = a
+        gstep = 5000 + 1000 * it
+        out[tag + "global_step"], out[tag + "calc_z"] = np.array(gstep), np.array(int(calc_z))
+
+        # ---- discriminator step (train_functions.py:55-57)
+        cgn.prep_disc_training()
+        handler.X, handler.Y = x_lab.tolist(), y_lab.tolist()
+        del masks[:]
+        torch.manual_seed(100 + it)
+        d_losses = disc_step(x_gen.tolist(), c_gen, 0)
+        assert len(masks) == 2
+        for nm, (i_, o_) in zip(("mask_labelled", "mask_generated"), masks):
+            m = torch.where(i_ != 0, o_ / torch.where(i_ != 0, i_, torch.ones_like(i_)), torch.full_like(i_, 1.0 / p_keep))
+            m = torch.where(m > 0.5 / p_keep, torch.full_like(m, 1.0 / p_keep), torch.zeros_like(m))  # exact {0, 1/keep}
+            assert torch.allclose(i_ * m, o_, rtol=1e-6, atol=0)
+            out[tag + nm] = m.numpy()
+        out[tag + "disc_losses"] = np.array([float(x) for x in d_losses])
+        for n, p in cgn.sentiment_discriminator.named_parameters():
+            out[tag + "disc_grad/" + n] = p.grad.detach().numpy().copy()
+
+        # ---- c inference (train_functions.py:81-82)
+        cgn.discriminator_mode(train_mode=False)
+        torch.manual_seed(200 + it)
+        c_batch = cgn.discriminator_forward(batch, B, False)
+        with torch.no_grad():  # the probabilities the draw was made from, by the reference's own modules (:163-167)
+            p1 = torch.softmax(cgn.sentiment_discriminator(cgn.embedding.get_word_embed(torch.from_numpy(batch[0]))), 1)[:, 1]
+        out[tag + "c"], out[tag + "c_p1"] = c_batch.numpy().copy(), p1.numpy().copy()
+
+        # ---- encoder / generator step (train_functions.py:85-90)
+        cgn.prep_enc_gen_training()
+        seed = 300 + it
+        torch.manual_seed(seed)
+        eg = enc_gen_step(batch, B, False, 0.0, c_batch, gstep, calc_z_loss=calc_z)
+        torch.manual_seed(seed)  # the same stream again: encode_for_z's randn calls (:96), in call order
+        out[tag + "eps"] = torch.randn([B, cfg.latent_variable_size]).numpy()
+        out[tag + "eps_recon"] = torch.randn([B, cfg.latent_variable_size]).numpy()
+        out[tag + "enc_gen_losses"] = np.array([float(x) for x in eg])
+        for n, p in cgn.named_parameters():
+            if n.startswith("sentiment_discriminator.") or p.grad is None:
+                continue
+            out[tag + "grad/" + n] = p.grad.detach().numpy().copy()
+        for k, v in cgn.state_dict().items():
+            out[tag + "after/" + k] = v.detach().numpy().copy()
+    hook.remove()
+    np.savez_compressed(OUT, **out)
+    print("wrote", OUT, "with", len(out), "arrays,", os.path.getsize(OUT), "bytes")
+    for it in range(2):
+        print("it", it, "disc", out["it%d/disc_losses" % it], "enc-gen", out["it%d/enc_gen_losses" % it])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,98 @@
+"""GPU: the HIP wake-sleep step through the drop-in closures of model/cgn.py against tests/golden/reference_step.npz =
+what the REFERENCE'S OWN closures computed (tests/golden/make_golden_step.py ran model/cgn.py's
+discriminator_sentiment_trainer().train and train_encoder_generator().train for two consecutive iterations on the
+CPU). Same initial state_dict, batches, eps, dropout masks and inferred c; compared are all losses, every gradient the
+reference's closures left in .grad, and every parameter after each iteration. Bar: 1e-4 relative (north_star, fp32);
+the fixture's model is tiny, so a ReLU / max-over-time kink within fp32 rounding would show as ONE tensor's gradient
+being off - the fixture was checked to have none for these seeds."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_step.npz"))
+
+
+def _rel(a, ref):
+    a = a.detach().double().cpu().reshape(-1)
+    ref = torch.from_numpy(np.asarray(ref)).double().reshape(-1)
+    return (a - ref).norm().item() / max(ref.norm().item(), 1e-30)
+
+
+class Handler:
+    def __init__(self):
+        self.X = self.Y = None
+
+    def get_sentiment_train_batch(self, i):
+        return self.X, self.Y
+
+    get_sentiment_dev_batch = get_sentiment_train_batch
+
+    def create_sentiment_batch(self, s):
+        return torch.tensor(s, dtype=torch.int64)
+
+
+def test_hip_step_matches_the_reference_closures(dev):
+    import ldrs_amd  # noqa: F401
+    from ldrs_amd.model.cgn import Controlled_Generation_Sentence
+    from ldrs_amd.utils.config import Config
+    W, Lmax, V, Cv, E, He, Z, Hg, Co, Ce = (int(v) for v in G["dims"])
+    cfg = Config(W, Lmax, V, Cv, float(G["learning_rate"]), 7.9, 0.1, 0.1, 1.0, word_embed_size=E,
+                 kernels=((1, 3), (2, 5), (3, 4)), encoder_rnn_size=He, latent_variable_size=Z, decoder_rnn_size=Hg,
+                 decoder_num_layers=2, sentiment_kernel_size=(3, 4, 5), sentiment_kernel_num=Co)
+    model = Controlled_Generation_Sentence(cfg, G["word_embed"])
+    model.load_state_dict({k[5:]: torch.from_numpy(G[k]) for k in G.files if k.startswith("init/")})
+    model = model.cuda()
+    model.kld_py2_floor = False  # the fixture was generated under Python 3 (true division in kld_coef)
+    handler = Handler()
+    disc_train = model.discriminator_sentiment_trainer(handler, True)
+    enc_gen_train = model.train_encoder_generator()
+    for it in range(2):
+        t = "it%d/" % it
+        d = {k[len(t):]: G[k] for k in G.files if k.startswith(t) and "/" not in k[len(t):]}
+        gstep, calc_z, B = int(d["global_step"]), bool(int(d["calc_z"])), d["enc_word"].shape[0]
+
+        model.prep_disc_training()
+        handler.X, handler.Y = d["x_labelled"].tolist(), d["y_labelled"].tolist()
+        cap = {}
+        d_h = disc_train(d["x_generated"].tolist(), torch.from_numpy(d["c_generated"]).float().view(B, -1), 0,
+                         mask_labelled=torch.from_numpy(d["mask_labelled"]).to(dev),
+                         mask_generated=torch.from_numpy(d["mask_generated"]).to(dev), capture=cap)
+        for a, b, nm in zip(d_h, d["disc_losses"], ("total", "ce_l", "gen_loss", "ce_g", "entropy")):
+            assert _rel(a, b) < TOL, ("disc loss", nm, it, _rel(a, b))
+        for k in (k for k in G.files if k.startswith(t + "disc_grad/")):
+            n = "sentiment_discriminator." + k[len(t) + 10:]
+            assert _rel(cap["disc_grads"][n], G[k]) < TOL, ("disc grad", n, it, _rel(cap["disc_grads"][n], G[k]))
+
+        # c inference: drive the Bernoulli draw with a uniform that reproduces the reference's recorded draw wherever
+        # the probabilities allow (u = 0 -> c = 1, u = 1 -> c = 0), and check the probabilities through it
+        batch = [d["enc_word"], d["enc_char"], d["dec_word"], None, d["target"]]
+        model.discriminator_mode(train_mode=False)
+        u = torch.from_numpy(np.where(d["c"] > 0.5, d["c_p1"] * 0.999, d["c_p1"] * 1.001 + 1e-7).astype(np.float32))
+        c_h = model.discriminator_forward(batch, B, True, uniform=u)
+        assert torch.equal(c_h.cpu().float().view(-1), torch.from_numpy(d["c"]).float().view(-1)), "c (p1 off by > 1e-3)"
+
+        model.prep_enc_gen_training()
+        cap = {}
+        eg = enc_gen_train(batch, B, True, 0.0, torch.from_numpy(d["c"]).float(), gstep, calc_z_loss=calc_z,
+                           eps=torch.from_numpy(d["eps"]), capture=cap)
+        names = ("ce", "kld", "z_loss", "c_loss", "kld_coef", "temp", "enc_loss", "gen_loss")
+        for a, b, nm in zip(eg, d["enc_gen_losses"], names):
+            a = a if isinstance(a, torch.Tensor) else torch.tensor(float(a))
+            if nm == "z_loss" and not calc_z:
+                assert float(a) == 0.0
+                continue
+            assert _rel(a, b) < TOL, ("enc-gen loss", nm, it, float(a), float(b))
+        mine = dict(cap["gen_grads"])
+        mine.update(cap["enc_grads"])
+        ref = {k[len(t) + 5:]: G[k] for k in G.files if k.startswith(t + "grad/")}
+        assert sorted(mine) == sorted(ref), (sorted(set(mine) ^ set(ref)))
+        for n, gref in ref.items():
+            assert _rel(mine[n], gref) < TOL, ("grad", n, it, _rel(mine[n], gref))
+        after = dict(model.named_parameters())
+        for k in (k for k in G.files if k.startswith(t + "after/")):
+            n = k[len(t) + 6:]
+            assert _rel(after[n], G[k]) < 1e-6, ("parameter after the iteration", n, it, _rel(after[n], G[k]))
