@@ -445,7 +445,6 @@ class CGNStep:
         # ---- temperature softmax + CE (cgn.py:1086-1092) -------------------------------------------------------
         tgt = target.reshape(-1)
         lse, nll, ce = ops.softmax_nll_fwd(logits, tgt, inv_tau, dyn=self._dyn())
-        dummy = lse  # any valid device pointer for unused GEMM operands (K = 0)
         need_soft = use_disc or calc_z_loss
         c_loss, z_loss = _new((1,), dev), _new((1,), dev)
         ops.fill(c_loss, 0.0)
@@ -505,7 +504,9 @@ class CGNStep:
         else:
             # CE only (initial VAE training, cgn.py:639-644): same epilogue with an empty product (K = 0)
             ops.fill(rowdot, 0.0)
-            ops.gemm(dummy.view(NT, 1)[:, :0], table.t()[:0], logits,
+            # (explicit K = 0 over real operands: torch hands out a NULL data_ptr for zero-element views)
+            ops.gemm(rowdot, table, logits, M=NT, N=V, K=0, a_m=Axis(1, 0, 0), a_k=LIN,
+                     b_k=LIN, b_n=Axis(table.stride(0), 0, 0),
                      softmax_bwd=dict(logits=logits, lse=lse, rowdot=rowdot, target=tgt, inv_tau=inv_tau,
                                       ce_scale=79.0 * inv_tau / NT), dyn=self._dyn())
         dlogits = logits

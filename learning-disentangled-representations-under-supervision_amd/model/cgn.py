@@ -257,7 +257,7 @@ class Controlled_Generation_Sentence(nn.Module):
     # ------------------------------------------------------------------------------------------------------------
     # initial VAE pre-training (cgn.py:621-674): one optimizer over every learnable parameter, no detach, no D
     # ------------------------------------------------------------------------------------------------------------
-    def _rvae_step(self, opts, input, i, dropout, train, eps=None, c=None):
+    def _rvae_step(self, opts, input, i, dropout, train, eps=None, c=None, capture=None):
         eng = self.step_engine()
         use_cuda = True
         enc_word, enc_char, dec_word, _, target = [None if v is None else _to_device_long(v, use_cuda).contiguous()
@@ -272,18 +272,18 @@ class Controlled_Generation_Sentence(nn.Module):
         ce, kld, _, _, enc_loss, _ = eng.enc_gen_train(
             opts, enc_word, enc_char, dec_word, target, c.to(eng.dev, t.float32).contiguous(),
             eps.to(eng.dev, t.float32).contiguous(), kc, 1.0, gen_drop_mask=mask, calc_z_loss=False, train=train,
-            use_disc=False, joint=True)
+            use_disc=False, joint=True, capture=capture)
         return ce, kld, kc, enc_loss  # loss = 79*ce + kld_coef*kld (cgn.py:641)
 
     def initial_rvae_trainer(self, data_handler):
         opts = [None]
 
-        def train(i, batch_size, use_cuda, dropout, start_index, eps=None, c=None):
+        def train(i, batch_size, use_cuda, dropout, start_index, eps=None, c=None, capture=None):
             input = data_handler.gen_batch_loader.next_batch(batch_size, 'train', start_index)
             eng = self.step_engine()
             if opts[0] is None or opts[0][0].arena is not eng.arenas["enc"]:
                 opts[0] = (eng.new_optimizer("enc"), eng.new_optimizer("gen"))
-            return self._rvae_step(opts[0], input, i, dropout, True, eps, c)
+            return self._rvae_step(opts[0], input, i, dropout, True, eps, c, capture)
 
         return train
 

@@ -1,7 +1,9 @@
 """Generates tests/golden/reference_step.npz by RUNNING the reference's own step closures (build container only):
 model/cgn.py  discriminator_sentiment_trainer().train (:269-341), discriminator_forward (:134-172) and
 train_encoder_generator().train (:1049-1154), in the order train_functions.py:24-90 calls them, on the CPU, for two
-consecutive wake-sleep iterations (the second one exercises Adam's moments and the updated weights).
+consecutive wake-sleep iterations (the second one exercises Adam's moments and the updated weights); then the
+validation closures valid_encoder_generator().valid (:1159-1250) and discriminator_sentiment_valid().valid (:174-240), and
+on a fresh model the initial VAE pre-training closures initial_rvae_trainer / initial_rvae_valid (:105-132, :621-674).
 
 Run as:  python -O tests/golden/make_golden_step.py      (-O: model/encoder.py:35 asserts on a helper that is not
 torch-2.x clean, utils/functional.py:13-15)
@@ -191,6 +193,62 @@ def main():
         for k, v in cgn.state_dict().items():
             out[tag + "after/" + k] = v.detach().numpy().copy()
     hook.remove()
+
+    # ---- validation closures on the trained-for-two-iterations model (forward only): valid_encoder_generator().valid
+    # (cgn.py:1159-1250) with the z pass, discriminator_sentiment_valid().valid (:174-240) with accuracies
+    cgn.prep_enc_gen_validation()
+    valid = cgn.valid_encoder_generator()
+    torch.manual_seed(400)
+    vl = valid(batch, B, False, c_batch, 7000, calc_z_loss=True)
+    torch.manual_seed(400)
+    out["valid/eps"] = torch.randn([B, cfg.latent_variable_size]).numpy()
+    out["valid/enc_gen_losses"] = np.array([float(x) for x in vl])
+    out["valid/c"], out["valid/global_step"] = c_batch.numpy().copy(), np.array(7000)
+    cgn.prep_disc_validation()
+    handler.get_sentiment_dev_batch = handler.get_sentiment_train_batch
+    dv = cgn.discriminator_sentiment_valid(handler, False, return_accuracy=True)(0, x_gen.tolist(), c_gen)
+    out["valid/disc"] = np.array([float(x) for x in dv])  # ce labelled, ce generated, correct, generated correct
+
+    # ---- initial VAE pre-training (cgn.py:105-132, 621-674; main.py:97-118): a FRESH model from the same initial
+    # state, two training steps (one Adam over every learnable parameter) and one validation step
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "word_embeddings.npy")
+        np.save(path, word_embed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            vae = cgn_mod.Controlled_Generation_Sentence(cfg, path)
+    vae.load_state_dict({k[5:]: torch.from_numpy(v) for k, v in out.items() if k.startswith("init/")})
+
+    class Loader:
+        def next_batch(self, batch_size, target, start_index):
+            return self.batch
+
+    handler.gen_batch_loader = Loader()
+    vae_train = vae.initial_rvae_trainer(handler)
+    vae_valid = vae.initial_rvae_valid(handler)
+    vae.prep_enc_gen_training()  # main.py:118
+    for it in range(2):
+        tag = "vae%d/" % it
+        handler.gen_batch_loader.batch = [out["it%d/%s" % (it, nm)] for nm in ("enc_word", "enc_char", "dec_word")] + \
+            [np.zeros((B, L + 1, cfg.max_word_len), np.int64), out["it%d/target" % it]]
+        torch.manual_seed(500 + it)
+        res = vae_train(3000 + 1000 * it, B, False, 0.0, 0)
+        torch.manual_seed(500 + it)  # train_rvae draws eps (:96) then c ~ Bernoulli(0.5) (:119-120), in that order
+        out[tag + "eps"] = torch.randn([B, cfg.latent_variable_size]).numpy()
+        out[tag + "c"] = torch.bernoulli(torch.ones(B, 1) * 0.5).numpy()
+        out[tag + "i"] = np.array(3000 + 1000 * it)
+        out[tag + "result"] = np.array([float(x) for x in res])  # ce, kld, kld_coef(i), loss
+        for n, p_ in vae.named_parameters():
+            if p_.grad is not None:
+                out[tag + "grad/" + n] = p_.grad.detach().numpy().copy()
+        for k, v in vae.state_dict().items():
+            out[tag + "after/" + k] = v.detach().numpy().copy()
+    vae.prep_enc_gen_validation()  # main.py:148
+    torch.manual_seed(600)
+    res = vae_valid(5000, B, False, 0.0, 0)
+    torch.manual_seed(600)
+    out["vaev/eps"] = torch.randn([B, cfg.latent_variable_size]).numpy()
+    out["vaev/c"] = torch.bernoulli(torch.ones(B, 1) * 0.5).numpy()
+    out["vaev/result"] = np.array([float(x) for x in res])
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, "with", len(out), "arrays,", os.path.getsize(OUT), "bytes")
     for it in range(2):

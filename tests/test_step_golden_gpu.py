@@ -96,3 +96,85 @@ def test_hip_step_matches_the_reference_closures(dev):
         for k in (k for k in G.files if k.startswith(t + "after/")):
             n = k[len(t) + 6:]
             assert _rel(after[n], G[k]) < 1e-6, ("parameter after the iteration", n, it, _rel(after[n], G[k]))
+
+
+def _model(dev):
+    import ldrs_amd  # noqa: F401
+    from ldrs_amd.model.cgn import Controlled_Generation_Sentence
+    from ldrs_amd.utils.config import Config
+    W, Lmax, V, Cv, E, He, Z, Hg, Co, Ce = (int(v) for v in G["dims"])
+    cfg = Config(W, Lmax, V, Cv, float(G["learning_rate"]), 7.9, 0.1, 0.1, 1.0, word_embed_size=E,
+                 kernels=((1, 3), (2, 5), (3, 4)), encoder_rnn_size=He, latent_variable_size=Z, decoder_rnn_size=Hg,
+                 decoder_num_layers=2, sentiment_kernel_size=(3, 4, 5), sentiment_kernel_num=Co)
+    model = Controlled_Generation_Sentence(cfg, G["word_embed"])
+    model.kld_py2_floor = False
+    return model
+
+
+def test_hip_validation_closures_match_the_reference(dev):
+    """valid_encoder_generator().valid (cgn.py:1159-1250, with the z pass) and discriminator_sentiment_valid().valid
+    (:174-240, with accuracies) on the weights the reference had after its two iterations."""
+    model = _model(dev)
+    model.load_state_dict({k[len("it1/after/"):]: torch.from_numpy(G[k]) for k in G.files if k.startswith("it1/after/")})
+    model = model.cuda()
+    B = G["it1/enc_word"].shape[0]
+    batch = [G["it1/enc_word"], G["it1/enc_char"], G["it1/dec_word"], None, G["it1/target"]]
+    model.prep_enc_gen_validation()
+    out = model.valid_encoder_generator()(batch, B, True, torch.from_numpy(G["valid/c"]).float(),
+                                          int(G["valid/global_step"]), calc_z_loss=True,
+                                          eps=torch.from_numpy(G["valid/eps"]))
+    for a, b, nm in zip(out, G["valid/enc_gen_losses"], ("ce", "kld", "z_loss", "c_loss", "kld_coef", "temp", "enc", "gen")):
+        a = a if isinstance(a, torch.Tensor) else torch.tensor(float(a))
+        assert _rel(a, b) < TOL, ("valid", nm, float(a), float(b))
+    handler = Handler()
+    handler.X, handler.Y = G["it1/x_labelled"].tolist(), G["it1/y_labelled"].tolist()
+    model.prep_disc_validation()
+    dv = model.discriminator_sentiment_valid(handler, True, return_accuracy=True)(
+        0, G["it1/x_generated"].tolist(), torch.from_numpy(G["it1/c_generated"]).float())
+    ref = G["valid/disc"]
+    assert _rel(dv[0], ref[0]) < TOL and _rel(dv[1], ref[1]) < TOL
+    assert int(dv[2]) == int(ref[2]) and int(dv[3]) == int(ref[3])
+
+
+def test_hip_initial_vae_step_matches_the_reference(dev):
+    """initial_rvae_trainer().train / initial_rvae_valid().valid (cgn.py:105-132, :621-674): two training steps from the
+    reference's initial state (one Adam over every learnable parameter), then a validation step."""
+    model = _model(dev)
+    model.load_state_dict({k[5:]: torch.from_numpy(G[k]) for k in G.files if k.startswith("init/")})
+    model = model.cuda()
+    B = G["it0/enc_word"].shape[0]
+
+    class Loader:
+        def next_batch(self, batch_size, target, start_index):
+            return self.batch
+
+    handler = Handler()
+    handler.gen_batch_loader = Loader()
+    train = model.initial_rvae_trainer(handler)
+    valid = model.initial_rvae_valid(handler)
+    model.prep_enc_gen_training()
+    for it in range(2):
+        t = "vae%d/" % it
+        handler.gen_batch_loader.batch = [G["it%d/%s" % (it, nm)] for nm in ("enc_word", "enc_char", "dec_word")] + \
+            [None, G["it%d/target" % it]]
+        cap = {}
+        res = train(int(G[t + "i"]), B, True, 0.0, 0, eps=torch.from_numpy(G[t + "eps"]),
+                    c=torch.from_numpy(G[t + "c"]), capture=cap)
+        for a, b, nm in zip(res, G[t + "result"], ("ce", "kld", "kld_coef", "loss")):
+            a = a if isinstance(a, torch.Tensor) else torch.tensor(float(a))
+            assert _rel(a, b) < TOL, ("vae", nm, it, float(a), float(b))
+        mine = dict(cap["gen_grads"])
+        mine.update(cap["enc_grads"])
+        ref = {k[len(t) + 5:]: G[k] for k in G.files if k.startswith(t + "grad/")}
+        assert sorted(mine) == sorted(ref), sorted(set(mine) ^ set(ref))
+        for n, gref in ref.items():
+            assert _rel(mine[n], gref) < TOL, ("vae grad", n, it, _rel(mine[n], gref))
+        after = dict(model.named_parameters())
+        for k in (k for k in G.files if k.startswith(t + "after/")):
+            n = k[len(t) + 6:]
+            assert _rel(after[n], G[k]) < 1e-6, ("vae parameter", n, it)
+    model.prep_enc_gen_validation()
+    res = valid(5000, B, True, 0.0, 0, eps=torch.from_numpy(G["vaev/eps"]), c=torch.from_numpy(G["vaev/c"]))
+    for a, b, nm in zip(res, G["vaev/result"], ("ce", "kld", "kld_coef", "loss")):
+        a = a if isinstance(a, torch.Tensor) else torch.tensor(float(a))
+        assert _rel(a, b) < TOL, ("vae valid", nm, float(a), float(b))
