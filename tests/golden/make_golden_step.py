@@ -17,8 +17,10 @@ reference is written to disk or into this repository:
         the squeeze only removed it again; torch >= 0.2 reductions drop it themselves and the squeeze then raises);
       - model/cgn.py:1097,1147   `backward(retain_variables=True)` -> `backward(retain_graph=True)`  (argument renamed
         in torch 0.2, old name removed later);
-  * model/encoder.py, model/generator.py, selfModules/highway.py, utils/functional.py, utils/config.py, utils/beam_search.py
-    are imported as they are.
+  * for the beam sampler (sample_from_generator, cgn.py:747-921) FOUR more, none touching arithmetic: the two places
+    where the reference hard-wires CUDA tensors (cgn.py:781 `cuda=True`, :845 `t.cuda.LongTensor`) use CPU tensors, and
+    the two Python-2 integer divisions (model/generator.py:31, utils/beam_search.py:88) are written `//`;
+  * model/encoder.py, selfModules/highway.py, utils/functional.py, utils/config.py are imported as they are.
 Everything else is the reference's code executing: the optimizers it builds, its gradient routing (the z.grad alias,
 generator step before the encoder backward), its losses. Schedules are evaluated under Python-3 division
 (kld_coef: true division, i.e. the oracle's py2_floor=False). Generator dropout is 0.0 (F.dropout's default
@@ -86,11 +88,19 @@ def main():
 
     exec_module("selfModules/tdnn.py", "selfModules.tdnn", "selfModules",
                 subs=[("x.max(2)[0].squeeze(2)", "x.max(2)[0]")], py2=False)
+    # sampler only (the forward pass of Generator is untouched): Python-2 integer divisions
+    exec_module("model/generator.py", "model.generator", "model",
+                subs=[("(beam_batch_size/zc.size(0))", "(beam_batch_size//zc.size(0))")], py2=False)
+    exec_module("utils/beam_search.py", "utils.beam_search", "utils",
+                subs=[("prev_k = bestScoresId / num_words", "prev_k = bestScoresId // num_words")], py2=False)
     with contextlib.redirect_stdout(io.StringIO()):
         exec_module("selfModules/embedding.py", "selfModules.embedding", "selfModules")
         exec_module("model/discriminator_sentiment.py", "model.discriminator_sentiment", "model")
         cgn_mod = exec_module("model/cgn.py", "model.cgn", "model",
-                              subs=[("backward(retain_variables=True)", "backward(retain_graph=True)")])
+                              subs=[("backward(retain_variables=True)", "backward(retain_graph=True)"),
+                                    # sampler: the reference hard-wires CUDA (cgn.py:781, :845); CPU tensors here
+                                    ("Beam(beam_size, batch_loader, cuda=True)", "Beam(beam_size, batch_loader, cuda=False)"),
+                                    ("active_idx = t.cuda.LongTensor(", "active_idx = t.LongTensor(")])
 
     cfg = Config(max_word_len=7, max_seq_len=5, word_vocab_size=50, char_vocab_size=20, learning_rate=5e-5,
                  lambda_c=7.9, lambda_z=0.1, lambda_u=0.1, beta=1.0)
@@ -208,6 +218,25 @@ def main():
     handler.get_sentiment_dev_batch = handler.get_sentiment_train_batch
     dv = cgn.discriminator_sentiment_valid(handler, False, return_accuracy=True)(0, x_gen.tolist(), c_gen)
     out["valid/disc"] = np.array([float(x) for x in dv])  # ce labelled, ce generated, correct, generated correct
+
+    # ---- sleep-phase beam sampler (cgn.py:747-921 + utils/beam_search.py + generator.only_decoder_beam) on the same
+    # trained-for-two-iterations model. No sentence reaches <eos> at the top of its beam within seq_len here (asserted
+    # below through equal lengths), so the reference's compaction of finished sentences (:843-869) - which mis-pairs
+    # seeds, SURVEY.md §8f - never runs: this pins the beam arithmetic itself.
+    class Vocab:
+        pad_token, go_token, end_token = "_", ">", "|"
+        word_to_idx = {"_": V - 3, ">": V - 2, "|": V - 1}
+
+    S_, K_, NB_ = 3, 4, 2
+    seed_zc = torch.randn(S_, cfg.latent_variable_size + 1, generator=g)
+    seed_zc[:, -1] = (seed_zc[:, -1] > 0).float()
+    codes, scores = cgn.sample_from_generator(Vocab(), cfg.max_seq_len, seed_zc.clone(), False, beam_size=K_, n_best=NB_,
+                                              samples=S_)
+    codes = np.asarray([[[int(w) for w in step] for step in sent] for sent in codes])  # [S, T, n_best]
+    assert codes.shape == (S_, cfg.max_seq_len, NB_), codes.shape
+    out["sampler/seed"], out["sampler/codes"] = seed_zc.numpy(), codes
+    out["sampler/scores"] = np.stack([sc.detach().numpy() for sc in scores])
+    out["sampler/params"] = np.array([S_, K_, NB_, cfg.max_seq_len])
 
     # ---- initial VAE pre-training (cgn.py:105-132, 621-674; main.py:97-118): a FRESH model from the same initial
     # state, two training steps (one Adam over every learnable parameter) and one validation step

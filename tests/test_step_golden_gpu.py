@@ -178,3 +178,31 @@ def test_hip_initial_vae_step_matches_the_reference(dev):
     for a, b, nm in zip(res, G["vaev/result"], ("ce", "kld", "kld_coef", "loss")):
         a = a if isinstance(a, torch.Tensor) else torch.tensor(float(a))
         assert _rel(a, b) < TOL, ("vae valid", nm, float(a), float(b))
+
+
+@pytest.mark.parametrize("graphed", [True, False])
+def test_hip_sampler_matches_the_reference_sampler(dev, graphed, monkeypatch):
+    """The on-device beam sampler against the token sequences and beam scores the reference's own
+    sample_from_generator produced (cgn.py:747-921; fixture without early-finished sentences)."""
+    from ldrs_amd.hip import sampler as hs
+    monkeypatch.setattr(hs.BeamSampler, "_cache", {})
+    orig_init = hs.BeamSampler.__init__
+    monkeypatch.setattr(hs.BeamSampler, "__init__", lambda self, eng, use_graph=True: orig_init(self, eng, graphed))
+    model = _model(dev)
+    model.load_state_dict({k[len("it1/after/"):]: torch.from_numpy(G[k]) for k in G.files if k.startswith("it1/after/")})
+    model = model.cuda()
+    S, K, NB, T = (int(v) for v in G["sampler/params"])
+    V = model.config.word_vocab_size
+
+    class Vocab:
+        pad_token, go_token, end_token = "_", ">", "|"
+        word_to_idx = {"_": V - 3, ">": V - 2, "|": V - 1}
+
+    codes, scores = model.sample_from_generator(Vocab(), T, torch.from_numpy(G["sampler/seed"]), True, beam_size=K,
+                                                n_best=NB, samples=S)
+    ref = G["sampler/codes"]
+    for s in range(S):
+        got = np.asarray([[int(w) for w in step] for step in codes[s]])
+        assert got.tolist() == ref[s].tolist(), (s, got.tolist(), ref[s].tolist())
+        for a, b in zip(scores[s].tolist(), G["sampler/scores"][s].tolist()):
+            assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (s, a, b)
