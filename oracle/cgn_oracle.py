@@ -20,6 +20,8 @@ outputs of the reference's own code run in the build container and committed as 
     (Python-2 files converted in memory with lib2to3; two textual substitutions for renamed / removed torch spellings,
     listed in that script). Every loss, every gradient the closures leave in .grad (incl. the z.grad alias routing)
     and every parameter after Adam agree with this file to fp32 rounding (most of them bit for bit).
+    The same fixture holds the reference's beam sampler run (sample_from_generator + Beam + only_decoder_beam): this
+    file's sample_from_generator reproduces its token sequences and scores.
 The multi-attribute extension (c_size > 1) has no counterpart in the reference: parity unpinned for it.
 """
 import math
