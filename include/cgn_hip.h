@@ -97,11 +97,12 @@ typedef struct cgn_gemm_desc {
 } cgn_gemm_desc;
 
 int cgn_gemm_f32(void* stream, const cgn_gemm_desc* desc /* host */);
-/* n <= 8 independent products in ONE launch (64x64 tiles, no split-K, linear epilogue, no A transform; all members
- * must have the same operand orientations). For the chains of small same-shaped convolution products: the six
+/* n <= 8 independent products in ONE launch (64x64 tiles, linear epilogue, no A transform; all members must have the
+ * same operand orientations and compute type). For the chains of small same-shaped convolution products: the six
  * char-TDNN widths (selfModules/tdnn.py:41-44, a Python loop over F.conv1d) and the text-CNN's filter widths
- * (model/discriminator_sentiment.py:64, a list comprehension over nn.Conv2d). Same results as n cgn_gemm_f32 calls
- * forced to tile 64 / split 1. */
+ * (model/discriminator_sentiment.py:64, a list comprehension over nn.Conv2d). A group with few tiles is split along K
+ * inside the launch (slabs in the FIRST member's workspace, one grouped reduce launch, fixed summation order);
+ * without a workspace it runs unsplit. Same results as n cgn_gemm_f32 calls up to fp32 summation order. */
 int cgn_gemm_group_f32(void* stream, const cgn_gemm_desc* descs /* host array */, int32_t n);
 /* Which kernel variant cgn_gemm_f32 would launch for `desc` (square tile 64|128, split-K factor, operand
  * orientations); used by bench.py to attribute per-launch timings to kernel symbols. Launches nothing. */

@@ -208,7 +208,8 @@ extern "C" int cgn_gemm_group_f32(void* stream, const cgn_gemm_desc* descs, int3
     GemmGroup g;
     g.n = 0;
     bool a_kc0 = false, b_kc0 = false, va = true, vb = true, bf16 = false;
-    long blocks = 0;
+    long tiles_total = 0, ws_floats = 0;
+    float* ws = nullptr;
     for (int i = 0; i < n; ++i) {
         const cgn_gemm_desc* d = descs + i;
         GemmParams p;
@@ -231,14 +232,57 @@ extern "C" int cgn_gemm_group_f32(void* stream, const cgn_gemm_desc* descs, int3
         p.tiles_n = cgn_cdiv(d->N, 64);
         p.splitk = 1;
         p.k_per_split = cgn_cdiv(d->K > 0 ? d->K : 1, KROUND) * KROUND;
+        p.ldw = (d->N + 3) / 4 * 4;
         p.order = 2;
-        blocks += (long)p.tiles_m * p.tiles_n;
-        CGN_CHECK_ARG(blocks < (1L << 30));
+        tiles_total += (long)p.tiles_m * p.tiles_n;
+        CGN_CHECK_ARG(tiles_total < (1L << 28));
+        if (g.n == 0) {
+            ws = d->workspace;
+            ws_floats = d->workspace ? d->workspace_bytes / (long)sizeof(float) : 0;
+        }
         g.p[g.n] = p;
-        g.tile_end[g.n] = (int)blocks;
         ++g.n;
     }
     if (g.n == 0) return CGN_OK;
+    // K split: a group with few tiles (the text-CNN: ~100 tiles of 30-50 K steps) is a latency chain on a fraction of
+    // the CUs; split every member so that ~768 blocks exist, each keeping >= 4 K steps. Slabs are carved out of the
+    // first member's workspace; without room the group runs unsplit.
+    int want = tiles_total >= 384 ? 1 : (int)((768 + tiles_total - 1) / tiles_total);
+    if (want > 8) want = 8;
+    long ws_off = 0;
+    bool any_split = false;
+    for (int pass = 0; pass < 2 && want > 1; ++pass) {  // pass 0: does it fit?  pass 1: commit
+        ws_off = 0;
+        for (int i = 0; i < g.n; ++i) {
+            GemmParams& p = g.p[i];
+            int sk = want;
+            if (sk > p.K / 128) sk = p.K / 128;
+            if (sk < 1) sk = 1;
+            const int kps = cgn_cdiv(cgn_cdiv(p.K > 0 ? p.K : 1, sk), KROUND) * KROUND;
+            sk = p.K > 0 ? cgn_cdiv(p.K, kps) : 1;
+            const long need = sk > 1 ? ((long)sk * p.M * p.ldw + 63) / 64 * 64 : 0;
+            if (pass == 1 && sk > 1) {
+                p.splitk = sk;
+                p.k_per_split = kps;
+                p.ws = ws + ws_off;
+                any_split = true;
+            }
+            ws_off += need;
+        }
+        if (pass == 0 && (ws == nullptr || ws_off > ws_floats)) want = 1;
+    }
+    long blocks = 0;
+    int max_reduce_blocks = 1;
+    for (int i = 0; i < g.n; ++i) {
+        const GemmParams& p = g.p[i];
+        blocks += (long)p.tiles_m * p.tiles_n * p.splitk;
+        g.tile_end[i] = (int)blocks;
+        if (p.splitk > 1) {
+            const int rb = cgn_cdiv((long)p.M * p.ldw / 4, 256);
+            if (rb > max_reduce_blocks) max_reduce_blocks = rb;
+        }
+    }
+    CGN_CHECK_ARG(blocks < (1L << 30));
     hipStream_t s = (hipStream_t)stream;
     const int vec = (va ? 1 : 0) | (vb ? 2 : 0);
     if (bf16)
@@ -246,5 +290,10 @@ extern "C" int cgn_gemm_group_f32(void* stream, const cgn_gemm_desc* descs, int3
     else
         launch_group_f32ops(g, vec, a_kc0, b_kc0, (unsigned)blocks, s);
     CGN_LAUNCH_CHECK();
+    if (any_split) {
+        if (max_reduce_blocks > 1024) max_reduce_blocks = 1024;
+        hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(max_reduce_blocks, g.n), dim3(256), 0, s, g);
+        CGN_LAUNCH_CHECK();
+    }
     return CGN_OK;
 }

@@ -549,13 +549,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
     gemm_tile<BT, A_KC, B_KC, VEC, EXP, S, BK, SMB, BF>(p, split, t);
 }
 
-// Grouped launch: up to GROUP_MAX independent products (same kernel variant, no split-K) in ONE launch; block b works
-// on the product whose tile range contains b. For chains of small same-shaped products (the six char-TDNN widths, the
+// Grouped launch: up to GROUP_MAX independent products (same kernel variant) in ONE launch; block b works on the
+// product whose block range contains b. Members may be split along K (slabs + one grouped reduce launch): the
+// text-CNN's products have ~100 tiles of 30-50 K steps in total, a latency chain per CU without the split. For chains of small same-shaped products (the six char-TDNN widths, the
 // text-CNN's filter widths) the launch boundaries and the drain/fill between them cost more than the arithmetic.
 constexpr int GROUP_MAX = 8;
 struct GemmGroup {
     GemmParams p[GROUP_MAX];
-    int tile_end[GROUP_MAX];  // running sum of tile counts
+    int tile_end[GROUP_MAX];  // running sum of block counts (tiles x K splits)
     int n;
 };
 
@@ -563,15 +564,17 @@ template <int BT, bool A_KC, bool B_KC, int VEC, int S, int BK = (BT == 128 ? 16
 __global__ __launch_bounds__(NT, 2) void gemm_group_kernel(const GemmGroup g) {
     int j = 0;
     while (j + 1 < g.n && (int)blockIdx.x >= g.tile_end[j]) ++j;  // block-uniform
-    const int t = blockIdx.x - (j ? g.tile_end[j - 1] : 0);
-    gemm_tile<BT, A_KC, B_KC, VEC, false, S, BK, false, BF>(g.p[j], 0, t);
+    const int local = blockIdx.x - (j ? g.tile_end[j - 1] : 0);  // (split, tile) of member j, tile fastest
+    const int ntiles = g.p[j].tiles_m * g.p[j].tiles_n;
+    const int split = local / ntiles;
+    gemm_tile<BT, A_KC, B_KC, VEC, false, S, BK, false, BF>(g.p[j], split, local - split * ntiles);
 }
 
 // Sums the split-K slabs in fixed order z = 0..splitk-1 (bitwise reproducible). Slab rows are ldw = ceil4(N) floats
 // apart, so every thread reads 16-byte quads whatever N is (N = 825 made the scalar form the common one: 13 us against
 // 6 us per launch). The slab loads of 4 splits are issued together before they are added: with one load per trip the
 // kernel was a chain of L2 round trips (12.7 us for 16 MB of slabs).
-static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
+__device__ __forceinline__ void splitk_reduce_body(const GemmParams& p) {
     const long total = (long)p.M * p.ldw;
     const long nvec = total / 4;
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
@@ -597,6 +600,13 @@ static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmPar
         for (int j = 0; j < 4; ++j)
             if (col + j < p.N) p.C[(long)row * p.ldc + col + j] = apply_epilogue(p, row, col + j, s[j]);
     }
+}
+
+static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) { splitk_reduce_body(p); }
+
+// one launch for all split members of a group: blockIdx.y = member
+static __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const GemmGroup g) {
+    if (g.p[blockIdx.y].splitk > 1) splitk_reduce_body(g.p[blockIdx.y]);
 }
 
 // BK per (tile, operand type): fp32 16 / 32 (measured, see above); bf16 operands take half the LDS per k and their MFMA
