@@ -9,19 +9,20 @@ anchor = sys.argv[3] if len(sys.argv) > 3 else "softmax_nll_fwd"
 c = sqlite3.connect(db)
 rows = c.execute("select name, start, end, grid_x, workgroup_x from kernels order by start").fetchall()
 marks = [i for i, r in enumerate(rows) if anchor in r[0]]
-# a step = from the first kernel after the previous step's last Adam to this step's last kernel; approximate by the
-# midpoint between consecutive anchors' positions in the launch order
-lo = (marks[which - 1] + marks[which]) // 2 if which > 0 else 0
-hi = (marks[which] + marks[which + 1]) // 2
-# refine: cut at the largest idle gap near lo / hi
-def cut(i):
-    best, bi = -1, i
-    for j in range(max(1, i - 60), min(len(rows) - 1, i + 60)):
-        gap = rows[j][1] - max(r[2] for r in rows[max(0, j - 8):j])
-        if gap > best:
-            best, bi = gap, j
-    return bi
-lo, hi = cut(lo), cut(hi)
+# a step (one graph replay) = n consecutive kernels in start order, n = the anchor spacing. Where a replay begins
+# relative to its anchor is found over ALL steady-state steps at once: the offset whose idle gaps add up to the most (a
+# graph launch leaves ~8-10 us every time, dependencies inside the graph leave <= 6 us and not at a fixed place).
+n = marks[which + 1] - marks[which]
+steady = [m for i, m in enumerate(marks[:-1]) if marks[i + 1] - m == n and m >= n]
+def gap_at(j):
+    return rows[j][1] - max(r[2] for r in rows[max(0, j - 8):j])
+best, off = -1, 0
+for a in range(n):
+    tot = sum(gap_at(m - a) for m in steady)
+    if tot > best:
+        best, off = tot, a
+lo = marks[which] - off
+hi = lo + n
 seg = rows[lo:hi]
 t0 = seg[0][1]
 end_max = 0

@@ -17,7 +17,7 @@ echo "# bench line printed under the profiler (tracing overhead included):"
 grep -h '^{"metric' $P/f32.log
 echo
 echo "# timeline of one replayed step under the profiler (tools/prof_timeline.py)"
-python3 tools/prof_timeline.py $P/f32/f32_results.db 8
+python3 tools/prof_timeline.py $P/f32/f32_results.db 20
 } > profiles/r01_step_kernel_summary.txt
 {
 echo "# OPTIONAL bf16 mode: rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --compute bf16  (MI355X, tools/collect_profiles.sh)"
@@ -28,5 +28,5 @@ echo "# bench line printed under the profiler:"
 grep -h '^{"metric' $P/bf16.log
 echo
 echo "# timeline of one replayed step under the profiler (tools/prof_timeline.py)"
-python3 tools/prof_timeline.py $P/bf16/bf16_results.db 8
+python3 tools/prof_timeline.py $P/bf16/bf16_results.db 20
 } > profiles/r01_bf16_step_kernel_summary.txt
