@@ -225,7 +225,7 @@ int cgn_act_maxpool_group_f32(void* stream, int32_t n, const float* const* conv 
 /* dX[b, 0:L, 0:E] (sentence stride sent_stride) from dfeat [B,F] through the kept windows; feat needed for tanh. */
 /* Dense route for the same dX (faster where every map's window would otherwise be walked on the VALU): (1) spread the
  * pooled gradient back over the convolution outputs, dconv[i] [B*(L-K_i+1), Co_i] = g at the kept position, 0 elsewhere
- * (dconv: host array of n device pointers); (2) dcols_i = dconv_i · W_i [Co_i, K_i*E] in window order (k, e) — a
+ * (dconv: host array of n 16-byte aligned device pointers); (2) dcols_i = dconv_i · W_i [Co_i, K_i*E] in window order (k, e) — a
  * cgn_gemm_group_f32 launch over the widths; (3) cgn_conv_col2im_f32 sums the overlapping windows:
  * dx[b,t,e] = sum_i sum_k dcols_i[(b, t-k), k*E + e]. Replaces the autograd backward of F.conv1d / nn.Conv2d + max
  * (selfModules/tdnn.py:42-43, model/discriminator_sentiment.py:64-66) wrt the input. */

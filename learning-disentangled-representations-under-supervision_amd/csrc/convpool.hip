@@ -119,28 +119,46 @@ struct ScatterGroup {
     long end[MAXW];  // running sum of B*P*Co
     int n, F, act;
 };
+// blockIdx.y = width; a thread produces 4 consecutive elements of that width's [B*P, Co] matrix (one 16-byte store;
+// one 32-bit division per thread instead of three 64-bit ones per element: 33 us -> see DESIGN.md for cfg2's char-TDNN).
 __global__ __launch_bounds__(256) void pool_bwd_scatter_kernel(const ScatterGroup g, const float* __restrict__ dfeat,
                                                                const float* __restrict__ feat,
                                                                const int32_t* __restrict__ arg) {
-    const long total = g.end[g.n - 1];
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        int j = 0;
-        while (j + 1 < g.n && i >= g.end[j]) ++j;
-        const long li = i - (j ? g.end[j - 1] : 0);
-        const int Co = g.Co[j], P = g.P[j];
-        const int co = (int)(li % Co);
-        const long bp = li / Co;
-        const int p = (int)(bp % P), b = (int)(bp / P);
-        const long fi = (long)b * g.F + g.col0[j] + co;
-        float v = 0.f;
-        if (arg[fi] == p) {
-            v = dfeat[fi];
-            if (g.act == ACT_TANH) {
-                const float y = feat[fi];
-                v *= (1.f - y * y);
+    const int j = blockIdx.y;
+    const unsigned size = (unsigned)(g.end[j] - (j ? g.end[j - 1] : 0));  // < 2^31 (host check)
+    const unsigned Co = (unsigned)g.Co[j], P = (unsigned)g.P[j];
+    float* out = g.dconv[j];
+    for (unsigned li = (blockIdx.x * 256u + threadIdx.x) * 4u; li < size; li += gridDim.x * 1024u) {
+        unsigned bp = li / Co;
+        unsigned co = li - bp * Co;
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned b = bp / P, p = bp - b * P;
+            const bool in = li + u < size;
+            const long fi = in ? (long)b * g.F + g.col0[j] + co : 0;
+            float x = 0.f;
+            if (in && arg[fi] == (int)p) {
+                x = dfeat[fi];
+                if (g.act == ACT_TANH) {
+                    const float y = feat[fi];
+                    x *= (1.f - y * y);
+                }
+            }
+            v[u] = x;
+            if (++co == Co) {
+                co = 0;
+                ++bp;
             }
         }
-        g.dconv[j][li] = v;
+        if (li + 3 < size) {
+            f32x4 w = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(out + li) = w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (li + u < size) out[li + u] = v[u];
+        }
     }
 }
 
@@ -418,19 +436,23 @@ extern "C" int cgn_pool_bwd_scatter_f32(void* stream, const cgn_conv_widths* wid
     if (rc) return rc;
     CGN_CHECK_ARG(dfeat && arg && (cw.act == ACT_RELU || feat));
     ScatterGroup g;
-    long end = 0;
+    long end = 0, max_size = 0;
     for (int i = 0; i < cw.n; ++i) {
-        CGN_CHECK_ARG(dconv[i] && cw.K[i] <= L);
+        CGN_CHECK_ARG(dconv[i] && cw.K[i] <= L && (uintptr_t)dconv[i] % 16 == 0);
         g.dconv[i] = dconv[i];
         g.P[i] = L - cw.K[i] + 1; g.Co[i] = cw.Co[i]; g.col0[i] = cw.col0[i];
-        end += (long)B * g.P[i] * g.Co[i];
+        const long size = (long)B * g.P[i] * g.Co[i];
+        CGN_CHECK_ARG(size < (1L << 31) - 4096L * 1024L);  // 32-bit element index inside a width (incl. the grid stride)
+        if (size > max_size) max_size = size;
+        end += size;
         g.end[i] = end;
     }
     g.n = cw.n; g.F = cw.F; g.act = cw.act;
-    long blocks = (end + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(pool_bwd_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, dfeat, feat,
-                       arg);
+    long blocks = (max_size / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pool_bwd_scatter_kernel, dim3((unsigned)blocks, (unsigned)g.n), dim3(256), 0, (hipStream_t)stream, g,
+                       dfeat, feat, arg);
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }

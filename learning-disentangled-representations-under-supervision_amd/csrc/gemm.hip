@@ -248,7 +248,7 @@ extern "C" int cgn_gemm_group_f32(void* stream, const cgn_gemm_desc* descs, int3
     // the CUs; split every member so that ~768 blocks exist, each keeping >= 4 K steps. Slabs are carved out of the
     // first member's workspace; without room the group runs unsplit.
     int want = tiles_total >= 384 ? 1 : (int)((768 + tiles_total - 1) / tiles_total);
-    if (want > 8) want = 8;
+    if (want > 64) want = 64;  // (each member is further limited to K / 128 splits below)
     long ws_off = 0;
     bool any_split = false;
     for (int pass = 0; pass < 2 && want > 1; ++pass) {  // pass 0: does it fit?  pass 1: commit

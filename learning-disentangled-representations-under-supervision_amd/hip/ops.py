@@ -713,10 +713,13 @@ def beam_topk(logits, lse, S, K, first, eos, pad, scores, done, length, tokens, 
           _ptr(hist_tok), _ptr(hist_org), _ptr(cand_val), _ptr(cand_idx))
 
 
-def conv_bwd_dx_dense(Ks, Cos, act, layout, W, dfeat, feat, arg, B, L, E, dx, sent_stride):
+def conv_bwd_dx_dense(Ks, Cos, act, layout, W, dfeat, feat, arg, B, L, E, dx, sent_stride, dW=None, x=None, beta=0.0):
     """Same result as conv_bwd_dx through the dense route (include/cgn_hip.h): scatter the pooled gradient over the
     convolution outputs, ONE grouped MFMA launch dcols_w = dconv_w @ W_w over the widths, col2im.
-    W[i]: weight of width i, [Co, K*E] rows (layout 0) or [Co, E, K] (layout 1, torch conv1d)."""
+    W[i]: weight of width i, [Co, K*E] rows (layout 0) or [Co, E, K] (layout 1, torch conv1d).
+    With dW (list, laid out like W) and x (the convolution's input, element (b,t,e) at b*sent_stride + t*E + e) the
+    weight gradients dW_w = beta*dW_w + dconv_w^T @ windows_w(x) come from a second grouped MFMA launch over the SAME
+    scattered matrices (same result as conv_bwd_dw without bias gradients; K = B*P is split inside the launch)."""
     n = len(Ks)
     cw = _conv_widths(Ks, Cos, act, layout)
     _chk_f32(dfeat, "dfeat"), _chk_f32(dx, "dx")
@@ -743,6 +746,21 @@ def conv_bwd_dx_dense(Ks, Cos, act, layout, W, dfeat, feat, arg, B, L, E, dx, se
         dconvs.append(dc), dcols.append(dl)
     ptrs = (C.c_void_p * n)(*[t_.data_ptr() for t_ in dconvs])
     _call("cgn_pool_bwd_scatter_f32", dev, C.byref(cw), _ptr(dfeat), _ptr(feat), _ptr(arg), B, L, ptrs)
+    if dW is not None:
+        _chk_f32(x, "x")
+        nx = x.untyped_storage().nbytes() // 4 - x.storage_offset()
+        _req((B - 1) * sent_stride + L * E <= nx, "x too small")
+        wcalls = []
+        for i in range(n):
+            K, Co = Ks[i], Cos[i]
+            P = L - K + 1
+            _req(dW[i].numel() == Co * K * E and dW[i].is_contiguous(), "conv dW %d" % i)
+            # A(m = map, k = (b,p)) = dconv[(b,p), map];  B(k = (b,p), n) = x[b, p + n // E, n % E] for layout 0,
+            # for layout 1 column n = c*K + j of the [Co, E, K] weight reads window element j*E + c
+            kw = dict(M=Co, N=K * E, K=B * P, a_m=Axis(1, 0, 0), a_k=Axis(Co, 0, 0), b_k=Axis(E, P, sent_stride),
+                      b_n=(Axis(1, 0, 0) if layout == 0 else Axis(E, K, 1)), beta=beta, compute="f32")
+            wcalls.append((dconvs[i], x, dW[i].view(Co, K * E), kw))
+        gemm_group(wcalls)
     gemm_group(calls)
     cptrs = (C.c_void_p * n)(*[t_.data_ptr() for t_ in dcols])
     Karr = (C.c_int32 * n)(*Ks)
