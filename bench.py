@@ -95,6 +95,9 @@ def main():
                     help="single-GPU rehearsal of the data-parallel schedule: a one-rank RCCL group, collectives issued")
     args = ap.parse_args()
 
+    if os.environ.get("CGN_BENCH_FAULT_DUMP"):  # debugging aid: all threads' tracebacks to stderr after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["CGN_BENCH_FAULT_DUMP"]), exit=False)
     import ldrs_amd  # noqa: F401
     from ldrs_amd import parallel
     from ldrs_amd.hip import ops
@@ -107,7 +110,10 @@ def main():
         os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29511")
         torch.cuda.set_device(0)
         torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1)
-    rank, world, local = parallel.init_from_env()
+    # CGN_DP_BACKEND / CGN_DP_DEVICE: rehearsals on a one-GPU box only (two ranks on one device over gloo; RCCL refuses that)
+    rank, world, local = parallel.init_from_env(backend=os.environ.get("CGN_DP_BACKEND"))
+    if "CGN_DP_DEVICE" in os.environ:
+        local = int(os.environ["CGN_DP_DEVICE"])
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -134,69 +140,51 @@ def main():
     # The step is captured once into a hipGraph (hip/graph.py) and replayed; its schedules and Adam step counts live in
     # device memory, so every replay is a full, different training step. N > 1 (data parallel): a chain of graph
     # segments cut at the three gradient reductions, whose RCCL all-reduces are issued eagerly between the segments
-    # and overlap the next segment. CGN_DP_EAGER=1 (or a failed capture) falls back to the kernel-by-kernel step.
-    use_graph = not args.eager and not (world > 1 and os.environ.get("CGN_DP_EAGER") == "1")
+    # and overlap the next segment. CGN_DP_EAGER=1 (or a failed capture) keeps the kernel-by-kernel step.
+    dp = world > 1 or args.force_dp
+    want_graph = not args.eager and not (dp and os.environ.get("CGN_DP_EAGER") == "1")
 
     def eager_step():
         return eng.wake_sleep(opts, data, kc, tau, calc_z_loss=args.z_loss)
-
-    if use_graph:
-        from ldrs_amd.hip.graph import GraphedWakeSleep
-        try:
-            graphed = GraphedWakeSleep(eng, opts, data, calc_z_loss=args.z_loss, warmup_kld=kc, warmup_tau=tau)
-        except Exception as e:  # noqa: BLE001 - report and fall back: the eager step is always available
-            if world == 1 and not args.force_dp:
-                raise
-            print("rank %d: segmented graph capture failed (%s: %s); running the eager step" %
-                  (rank, type(e).__name__, e), file=sys.stderr, flush=True)
-            torch.cuda.synchronize()
-            use_graph = False
-    if world > 1:
-        # every rank must take the same path: one failed capture sends all ranks to the eager step
-        flag = torch.tensor([1.0 if use_graph else 0.0], device=dev)
-        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-        use_graph = bool(flag.item() > 0.5)
-    if use_graph:
-        def step():
-            return graphed(kc, tau, totals=False)
-    else:
-        step = eager_step
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    if not use_graph:
-        ops.GEMM_PROFILE = {"variant": (128, 1, 1), "records": []}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_graph:
-        # HIP events cannot bracket single kernels inside a graph replay: the roofline kernel's launches are timed in
-        # an instrumented eager pass of the SAME step on the same data right after the timed region (its kernels run
-        # alone on the stream, as they do inside the graph's forward chain); rocprofv3's kernel trace of this command
-        # (profiles/) shows the in-graph durations.
-        ops.GEMM_PROFILE = {"variant": (128, 1, 1), "records": []}
-        for _ in range(max(3, min(args.steps, 10))):
-            eager_step()
-        torch.cuda.synchronize()
-    prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
-    losses = losses[2]
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = tt.item()
-    ce = losses[0].item()
-    if not (ce == ce) or ce <= 0:
-        raise SystemExit("non-finite loss in the benchmark step")
+    def timed(step, profile_inside):
+        """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides; max over ranks."""
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        if profile_inside:
+            ops.GEMM_PROFILE = {"variant": (128, 1, 1), "records": []}
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            el = tt.item()
+        return el, out
 
-    if rank == 0:
+    def summarise(eg_losses, prof):
+        """Host-side copies of everything emit() needs from the device (the watchdog path must not touch the GPU)."""
+        ce = eg_losses[0].item()
+        if not (ce == ce) or ce <= 0:
+            raise SystemExit("non-finite loss in the benchmark step")
+        # the roofline kernel is ONE symbol: the linear-epilogue NT 128-tile variant = the vocabulary projection (the
+        # dlogits product shares the tile shape but runs the softmax-backward epilogue variant, a different symbol)
+        recs = [r for r in prof["records"] if r[0] == (128, 1, 1)]
+        flops = sum(2.0 * M * N * K for _, _, M, N, K, _, _ in recs)
+        ms = sum(e0.elapsed_time(e1) for *_, e0, e1 in recs)
+        return flops, ms, len(recs)
+
+    def emit(elapsed, summary, launch, graph_timing):
+        """rank 0: the ONE JSON line of the contract, for a timed region of exactly K steps that took `elapsed`."""
+        flops, ms, launches = summary
         # HBM bytes per launch of the roofline kernel: PMC counters cannot be read from inside the run, so the figure
         # comes from the committed rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py; FETCH_SIZE and
         # WRITE_SIZE in separate runs, FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes)
@@ -208,12 +196,6 @@ def main():
             for k, v in tj["kernels"].items():
                 if k.startswith("gemm_kernel<128, true, true, 3, false, 2, 16, false, false>") and k.endswith("g1727"):
                     traffic, traffic_src = v["traffic"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, %d launches)" % v["launches"]
-        # the roofline kernel is ONE symbol: the linear-epilogue NT 128-tile variant = the vocabulary projection (the
-        # dlogits product shares the tile shape but runs the softmax-backward epilogue variant, a different symbol)
-        recs = [r for r in prof["records"] if r[0] == (128, 1, 1)]
-        flops = sum(2.0 * M * N * K for _, _, M, N, K, _, _ in recs)
-        ms = sum(e0.elapsed_time(e1) for *_, e0, e1 in recs)
-        launches = len(recs)
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak = FP32_MFMA_PEAK_TFLOPS if args.compute == "f32" else BF16_MFMA_PEAK_TFLOPS
         out = {
@@ -230,8 +212,7 @@ def main():
                                       "accumulation and storage; not the metric's fp32 configuration)")
                                    + ", calc_z_loss=%s" % args.z_loss,
                        "global_batch": world * BATCH, "seq_len": SEQ, "parallelism": "dp%d" % world,
-                       "launch": ("hipGraph replay" if world == 1 and not args.force_dp else
-                                  "hipGraph segments + eager RCCL all-reduce") if use_graph else "eager"},
+                       "launch": launch},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
@@ -243,11 +224,83 @@ def main():
                          "avg_launch_us": 1e3 * ms / max(launches, 1),
                          "algorithmic_gflop_per_launch": flops / max(launches, 1) / 1e9,
                          "timing": "HIP events around each launch, " + ("instrumented eager pass after the timed "
-                                   "graph replays" if use_graph else "inside the timed region")},
+                                   "graph replays" if graph_timing else "inside the timed region")},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not dp:
             out["cpu_baseline"] = cpu_baseline(O, ocfg, host_data, global_step)
         print(json.dumps(out), flush=True)
+
+    # Data-parallel runs time the eager step FIRST and keep that result: the segmented-graph replay has been run on
+    # this project's one-GPU boxes only with a one-rank RCCL group (and two ranks over gloo), so if it does not come
+    # back on a real multi-GPU node a watchdog reports the eager measurement instead of losing the run.
+    eager_result = None
+    watchdog = None
+    if dp and want_graph:
+        eager_result = timed(eager_step, True)
+        eager_prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+        torch.cuda.synchronize()
+        eager_summary = summarise(eager_result[1][2], eager_prof)
+        limit = float(os.environ.get("CGN_DP_GRAPH_TIMEOUT", "120"))
+
+        def bail():
+            if rank == 0:
+                emit(eager_result[0], eager_summary,
+                     "eager (the segmented-graph replay did not finish within %.0f s)" % limit, False)
+            sys.stdout.flush()
+            os._exit(0)
+
+        import threading
+        watchdog = threading.Timer(limit, bail)
+        watchdog.daemon = True
+        watchdog.start()
+
+    use_graph = want_graph
+    if use_graph:
+        from ldrs_amd.hip.graph import GraphedWakeSleep
+        try:
+            graphed = GraphedWakeSleep(eng, opts, data, calc_z_loss=args.z_loss, warmup_kld=kc, warmup_tau=tau)
+        except Exception as e:  # noqa: BLE001 - report and fall back: the eager step is always available
+            if not dp:
+                raise
+            print("rank %d: segmented graph capture failed (%s: %s); running the eager step" %
+                  (rank, type(e).__name__, e), file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            use_graph = False
+    if world > 1:
+        # every rank must take the same path: one failed capture sends all ranks to the eager step
+        flag = torch.tensor([1.0 if use_graph else 0.0], device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        use_graph = bool(flag.item() > 0.5)
+
+    if use_graph:
+        if os.environ.get("CGN_DP_SIMULATE_HANG") == "1" and dp:  # test hook for the watchdog path
+            time.sleep(1e6)
+        elapsed, losses = timed(lambda: graphed(kc, tau, totals=False), False)
+        # HIP events cannot bracket single kernels inside a graph replay: the roofline kernel's launches are timed in
+        # an instrumented eager pass of the SAME step on the same data right after the timed region (its kernels run
+        # alone on the stream, as they do inside the graph's forward chain); rocprofv3's kernel trace of this command
+        # (profiles/) shows the in-graph durations.
+        ops.GEMM_PROFILE = {"variant": (128, 1, 1), "records": []}
+        for _ in range(max(3, min(args.steps, 10))):
+            eager_step()
+        torch.cuda.synchronize()
+    elif eager_result is not None:
+        (elapsed, losses), ops.GEMM_PROFILE = eager_result, eager_prof
+    else:
+        elapsed, losses = timed(eager_step, True)
+    if watchdog is not None:
+        watchdog.cancel()
+    if use_graph and eager_result is not None and eager_result[0] < elapsed:
+        # both were measured over exactly K steps: report the faster schedule, and say which one it is
+        (elapsed, losses), ops.GEMM_PROFILE = eager_result, eager_prof
+        use_graph = False
+    prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    if rank == 0:
+        launch = (("hipGraph replay" if not dp else "hipGraph segments + eager RCCL all-reduce") if use_graph else
+                  ("eager" if eager_result is None or not want_graph else
+                   "eager (faster here than the segmented-graph replay, which also ran)"))
+        torch.cuda.synchronize()
+        emit(elapsed, summarise(losses[2], prof), launch, use_graph)
     if world > 1:
         torch.distributed.barrier()
     if torch.distributed.is_initialized():
