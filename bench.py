@@ -230,6 +230,17 @@ def main():
             out["cpu_baseline"] = cpu_baseline(O, ocfg, host_data, global_step)
         print(json.dumps(out), flush=True)
 
+    def replicas_identical():
+        """Data parallel: every rank must hold bit-identical weights after any number of steps (same initial weights,
+        same reduced gradients). A broken reduction shows up here at once, since the ranks train on different shards."""
+        chk = torch.stack([a.p.double().sum() for a in eng.arenas.values()] +
+                          [a.p.double().abs().sum() for a in eng.arenas.values()])
+        if world == 1:
+            return True
+        both = torch.stack([chk, -chk])
+        torch.distributed.all_reduce(both, op=torch.distributed.ReduceOp.MAX)  # max(x) == -max(-x)  <=>  all equal
+        return bool(torch.equal(both[0], -both[1]))
+
     # Data-parallel runs time the eager step FIRST and keep that result: the segmented-graph replay has been run on
     # this project's one-GPU boxes only with a one-rank RCCL group (and two ranks over gloo), so if it does not come
     # back on a real multi-GPU node a watchdog reports the eager measurement instead of losing the run.
@@ -240,6 +251,8 @@ def main():
         eager_prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
         torch.cuda.synchronize()
         eager_summary = summarise(eager_result[1][2], eager_prof)
+        if not replicas_identical():
+            raise SystemExit("data-parallel replicas diverged in the eager schedule")
         limit = float(os.environ.get("CGN_DP_GRAPH_TIMEOUT", "120"))
 
         def bail():
@@ -290,6 +303,12 @@ def main():
         elapsed, losses = timed(eager_step, True)
     if watchdog is not None:
         watchdog.cancel()
+    if dp and use_graph and not replicas_identical():
+        # never seen; if the replayed schedule ever lost a reduction, the eager measurement (checked above) stands
+        print("rank %d: replicas diverged under the segmented-graph replay; reporting the eager schedule" % rank,
+              file=sys.stderr, flush=True)
+        (elapsed, losses), ops.GEMM_PROFILE = eager_result, eager_prof
+        use_graph = False
     if use_graph and eager_result is not None and eager_result[0] < elapsed:
         # both were measured over exactly K steps: report the faster schedule, and say which one it is
         (elapsed, losses), ops.GEMM_PROFILE = eager_result, eager_prof
