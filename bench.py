@@ -230,6 +230,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline(O, ocfg, host_data, global_step)
         print(json.dumps(out), flush=True)
 
+    def check_lstm():
+        """The persistent LSTM launches need their workgroups resident together; a bounded wait that runs out leaves a
+        sticky flag (include/cgn_hip.h). A run with the flag set is not a measurement of a correct step."""
+        if ops.lstm_sticky_timeouts():
+            raise SystemExit("a persistent LSTM launch timed out (invalid results): rerun with CGN_LSTM_PERSISTENT=0")
+
     def replicas_identical():
         """Data parallel: every rank must hold bit-identical weights after any number of steps (same initial weights,
         same reduced gradients). A broken reduction shows up here at once, since the ranks train on different shards."""
@@ -253,6 +259,7 @@ def main():
         eager_summary = summarise(eager_result[1][2], eager_prof)
         if not replicas_identical():
             raise SystemExit("data-parallel replicas diverged in the eager schedule")
+        check_lstm()
         limit = float(os.environ.get("CGN_DP_GRAPH_TIMEOUT", "120"))
 
         def bail():
@@ -314,6 +321,8 @@ def main():
         (elapsed, losses), ops.GEMM_PROFILE = eager_result, eager_prof
         use_graph = False
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    torch.cuda.synchronize()
+    check_lstm()
     if rank == 0:
         launch = (("hipGraph replay" if not dp else "hipGraph segments + eager RCCL all-reduce") if use_graph else
                   ("eager" if eager_result is None or not want_graph else

@@ -306,7 +306,7 @@ constexpr int SYNC_STRIDE = 32;  // u32 words per counter: one 128-byte line eac
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ bool group_wait(unsigned* cnt, unsigned target, unsigned* tmo) {
+__device__ __forceinline__ bool group_wait(unsigned* cnt, unsigned target, unsigned* tmo, unsigned* sticky) {
     unsigned spins = 0;
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
@@ -314,6 +314,7 @@ __device__ __forceinline__ bool group_wait(unsigned* cnt, unsigned target, unsig
         if (spins > PERSIST_SPIN_LIMIT ||
             ((spins & 63u) == 0u && __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
             __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // never cleared by the library
             return false;
         }
     }
@@ -331,7 +332,7 @@ __device__ __forceinline__ void st_sc1(float* p, float v) {
 
 // CPW: chunks (of 16 k) per wave held in registers; H <= 128 * CPW.
 template <int CPW>
-__global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_kernel(const FwdParams p, unsigned* sync) {
+__global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_kernel(const FwdParams p, unsigned* sync, unsigned* sticky) {
     __shared__ float red[LSTM_NW][16][64];
     __shared__ int s_ok;
     const int B = p.B, T = p.T, H = p.H;
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_kernel(const FwdPara
             for (int g = 0; g < 4; ++g) pre_x[g] = xg[g * H];
         }
         if (step > 0) {
-            if (threadIdx.x == 0) s_ok = group_wait(cnt, (unsigned)(NJ * step), tmo) ? 1 : 0;
+            if (threadIdx.x == 0) s_ok = group_wait(cnt, (unsigned)(NJ * step), tmo, sticky) ? 1 : 0;
             __syncthreads();
             if (!s_ok) break;  // workgroup-uniform
         }
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_kernel(const FwdPara
 
 // CPW: chunks (of 16 k over K = 4H) per wave held in registers; H <= 32 * CPW.
 template <int CPW>
-__global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdParams p, unsigned* sync) {
+__global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdParams p, unsigned* sync, unsigned* sticky) {
     __shared__ float red[LSTM_NW][4][64];
     __shared__ int s_ok;
     const int B = p.B, T = p.T, H = p.H;
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdPara
 
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         if (step > 0) {
-            if (threadIdx.x == 0) s_ok = group_wait(cnt, (unsigned)(NJ * step), tmo) ? 1 : 0;
+            if (threadIdx.x == 0) s_ok = group_wait(cnt, (unsigned)(NJ * step), tmo, sticky) ? 1 : 0;
             __syncthreads();
             if (!s_ok) break;  // workgroup-uniform
             const int aoff = (bA * T + t_next) * K * 4;
@@ -590,7 +591,10 @@ bool persist_ok(int nseq, int B, int T, int H) {
     return true;
 }
 
-long persist_sync_bytes(int nseq, int B) { return ((long)nseq * cgn_cdiv(B, 16) + 1) * SYNC_STRIDE * 4; }
+// scratch layout: one 128-byte line per group counter, one for the per-launch timeout word (all zeroed by every launch),
+// and, as the LAST line of whatever the caller passed, a sticky timeout flag that the library sets and never clears
+long persist_zero_bytes(int nseq, int B) { return ((long)nseq * cgn_cdiv(B, 16) + 1) * SYNC_STRIDE * 4; }
+long persist_sync_bytes(int nseq, int B) { return persist_zero_bytes(nseq, B) + SYNC_STRIDE * 4; }
 
 }  // namespace
 
@@ -674,12 +678,14 @@ extern "C" int cgn_lstm_seq_fwd_persistent_f32(void* stream, const cgn_lstm_fwd_
     }
     p.B = B; p.T = T; p.H = H; p.nseq = nseq; p.step = 0;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sync_ws, 0, (size_t)need, st) != hipSuccess) return CGN_ERR_HIP_BASE + (int)hipGetLastError();
+    if (hipMemsetAsync(sync_ws, 0, (size_t)persist_zero_bytes(nseq, B), st) != hipSuccess)
+        return CGN_ERR_HIP_BASE + (int)hipGetLastError();
+    unsigned* sticky = (unsigned*)((char*)sync_ws + (sync_ws_bytes / 128 - 1) * 128);
     dim3 grid(nseq * cgn_cdiv(B, 16) * (H / 16));
     if (H <= 256)
-        hipLaunchKernelGGL((lstm_persist_fwd_kernel<2>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws);
+        hipLaunchKernelGGL((lstm_persist_fwd_kernel<2>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws, sticky);
     else
-        hipLaunchKernelGGL((lstm_persist_fwd_kernel<4>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws);
+        hipLaunchKernelGGL((lstm_persist_fwd_kernel<4>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws, sticky);
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }
@@ -702,12 +708,14 @@ extern "C" int cgn_lstm_seq_bwd_persistent_f32(void* stream, const cgn_lstm_bwd_
     }
     p.B = B; p.T = T; p.H = H; p.nseq = nseq; p.step = 0;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sync_ws, 0, (size_t)need, st) != hipSuccess) return CGN_ERR_HIP_BASE + (int)hipGetLastError();
+    if (hipMemsetAsync(sync_ws, 0, (size_t)persist_zero_bytes(nseq, B), st) != hipSuccess)
+        return CGN_ERR_HIP_BASE + (int)hipGetLastError();
+    unsigned* sticky = (unsigned*)((char*)sync_ws + (sync_ws_bytes / 128 - 1) * 128);
     dim3 grid(nseq * cgn_cdiv(B, 16) * (H / 16));
     if (H <= 256)
-        hipLaunchKernelGGL((lstm_persist_bwd_kernel<8>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws);
+        hipLaunchKernelGGL((lstm_persist_bwd_kernel<8>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws, sticky);
     else
-        hipLaunchKernelGGL((lstm_persist_bwd_kernel<16>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws);
+        hipLaunchKernelGGL((lstm_persist_bwd_kernel<16>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws, sticky);
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }

@@ -567,7 +567,14 @@ def lstm_persistent_bytes(nseq, B, T, H, dev):
 def lstm_timeout_word(dev, nseq, B, T, H):
     """The timeout word of the last persistent launch of this shape on the current stream (0 = every wait was met)."""
     n = lstm_persistent_bytes(nseq, B, T, H, dev)
-    return int(_lstm_sync_ws(dev)[n // 4 - 32].item()) if n else 0
+    return int(_lstm_sync_ws(dev)[n // 4 - 64].item()) if n else 0
+
+
+def lstm_sticky_timeouts():
+    """Number of persistent-LSTM scratch buffers (one per device and stream) whose STICKY timeout flag is set: non-zero
+    means some persistent launch since start-up ran out of a bounded wait and produced invalid results (a co-scheduled
+    kernel kept its workgroups from becoming resident together). One device read per buffer; synchronises."""
+    return sum(int(ws[-32].item() != 0) for ws in _lstm_sync.values())
 
 
 def lstm_seq_fwd(seqs, B, T, H):

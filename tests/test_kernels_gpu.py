@@ -59,6 +59,7 @@ def test_lstm_fwd_bwd(dev, B, T, H, Din, bidir, persistent, monkeypatch):
         seqs.append(s)
     engine.lstm_run_fwd(seqs, [P["weight_hh_l0" + sfx] for sfx, _ in dirs])
     assert ops.lstm_timeout_word(dev, nseq, B, T, H) == 0
+    assert ops.lstm_sticky_timeouts() == 0
     for di, (s, (sfx, rev)) in enumerate(zip(seqs, dirs)):
         hout = s.hbuf[:, :T] if rev else s.hbuf[:, 1:]
         assert rel(hout, out[:, :, di * H:(di + 1) * H]) < TOL
@@ -71,6 +72,7 @@ def test_lstm_fwd_bwd(dev, B, T, H, Din, bidir, persistent, monkeypatch):
         dcs.append(w_c[di].float().contiguous().to(dev))
     dgs = engine.lstm_run_bwd(seqs, [P["weight_hh_l0" + sfx] for sfx, _ in dirs], exts, [None] * len(dirs), dcs)
     assert ops.lstm_timeout_word(dev, nseq, B, T, H) == 0
+    assert ops.lstm_sticky_timeouts() == 0
     dx = torch.zeros(B * T, Din, device=dev)
     for di, (s, (sfx, rev)) in enumerate(zip(seqs, dirs)):
         G = {k: torch.full_like(P[k + sfx], float("nan")) for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0",
