@@ -252,11 +252,28 @@ def main():
     # back on a real multi-GPU node a watchdog reports the eager measurement instead of losing the run.
     eager_result = None
     watchdog = None
+    lstm_note = ""
     if dp and want_graph:
         eager_result = timed(eager_step, True)
         eager_prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
         torch.cuda.synchronize()
         eager_summary = summarise(eager_result[1][2], eager_prof)
+        # A persistent LSTM launch that timed out on ANY rank (its workgroups could not become resident together, e.g.
+        # beside a collective's kernels) invalidates the run: all ranks switch to the per-timestep kernels and repeat.
+        bad = torch.tensor([float(ops.lstm_sticky_timeouts()) +
+                            (1.0 if os.environ.get("CGN_DP_SIMULATE_LSTM_TIMEOUT") == "1" else 0.0)], device=dev)  # test hook
+        if world > 1:
+            torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
+        if bad.item() > 0:
+            print("rank %d: a persistent LSTM launch timed out; repeating with the per-timestep kernels" % rank,
+                  file=sys.stderr, flush=True)
+            ops.LSTM_PERSISTENT = False
+            ops.clear_lstm_sticky_timeouts()
+            lstm_note = ", per-timestep LSTM kernels (a persistent launch timed out beside the collectives)"
+            eager_result = timed(eager_step, True)
+            eager_prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+            torch.cuda.synchronize()
+            eager_summary = summarise(eager_result[1][2], eager_prof)
         if not replicas_identical():
             raise SystemExit("data-parallel replicas diverged in the eager schedule")
         check_lstm()
@@ -265,7 +282,7 @@ def main():
         def bail():
             if rank == 0:
                 emit(eager_result[0], eager_summary,
-                     "eager (the segmented-graph replay did not finish within %.0f s)" % limit, False)
+                     "eager (the segmented-graph replay did not finish within %.0f s)" % limit + lstm_note, False)
             sys.stdout.flush()
             os._exit(0)
 
@@ -328,7 +345,7 @@ def main():
                   ("eager" if eager_result is None or not want_graph else
                    "eager (faster here than the segmented-graph replay, which also ran)"))
         torch.cuda.synchronize()
-        emit(elapsed, summarise(losses[2], prof), launch, use_graph)
+        emit(elapsed, summarise(losses[2], prof), launch + lstm_note, use_graph)
     if world > 1:
         torch.distributed.barrier()
     if torch.distributed.is_initialized():

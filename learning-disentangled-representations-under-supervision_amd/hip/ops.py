@@ -577,6 +577,11 @@ def lstm_sticky_timeouts():
     return sum(int(ws[-32].item() != 0) for ws in _lstm_sync.values())
 
 
+def clear_lstm_sticky_timeouts():
+    for ws in _lstm_sync.values():
+        ws[-32:].zero_()
+
+
 def lstm_seq_fwd(seqs, B, T, H):
     """seqs: list of dicts(xg, xg_extra=None, w_hh, hbuf, cbuf, gates, reverse)."""
     arr = (_lib.LstmFwdSeq * len(seqs))()
