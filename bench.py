@@ -327,12 +327,19 @@ def main():
         elapsed, losses = timed(eager_step, True)
     if watchdog is not None:
         watchdog.cancel()
-    if dp and use_graph and not replicas_identical():
-        # never seen; if the replayed schedule ever lost a reduction, the eager measurement (checked above) stands
-        print("rank %d: replicas diverged under the segmented-graph replay; reporting the eager schedule" % rank,
-              file=sys.stderr, flush=True)
-        (elapsed, losses), ops.GEMM_PROFILE = eager_result, eager_prof
-        use_graph = False
+    if dp and use_graph:
+        torch.cuda.synchronize()
+        bad = torch.tensor([float(ops.lstm_sticky_timeouts())], device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
+        if bad.item() > 0 or not replicas_identical():
+            # never seen; if the replayed schedule ever lost a reduction or starved a persistent launch, the eager
+            # measurement (checked above) stands
+            print("rank %d: the segmented-graph replay left %s; reporting the eager schedule" %
+                  (rank, "a timed-out LSTM launch" if bad.item() > 0 else "diverged replicas"), file=sys.stderr, flush=True)
+            ops.clear_lstm_sticky_timeouts()
+            (elapsed, losses), ops.GEMM_PROFILE = eager_result, eager_prof
+            use_graph = False
     if use_graph and eager_result is not None and eager_result[0] < elapsed:
         # both were measured over exactly K steps: report the faster schedule, and say which one it is
         (elapsed, losses), ops.GEMM_PROFILE = eager_result, eager_prof
