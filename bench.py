@@ -43,9 +43,9 @@ def make_config(Config, cfgd=None):
     return Config(*pos, 5e-5, 7.9, 0.1, 0.1, 1.0, **kw)
 
 
-def device_data(O, ocfg, B, L, seed, dev, drop_p=0.3):
-    d = O.synthetic_batch(ocfg, B, L, seed=seed)
-    F_ = len(ocfg.sentiment_kernel_size) * ocfg.sentiment_kernel_num
+def device_data(synthetic, cfg, B, L, seed, dev, drop_p=0.3):
+    d = synthetic.synthetic_batch(cfg, B, L, seed=seed)
+    F_ = len(cfg.sentiment_kernel_size) * cfg.sentiment_kernel_num
     g = torch.Generator().manual_seed(seed + 1)
     keep = 1.0 - drop_p
     d["mask_labelled"] = (torch.rand(B, F_, generator=g) < keep).float() / keep
@@ -53,8 +53,11 @@ def device_data(O, ocfg, B, L, seed, dev, drop_p=0.3):
     return {k: v.to(dev).contiguous() for k, v in d.items()}, d
 
 
-def cpu_baseline(O, ocfg, host_data, global_step, budget_s=25.0):
-    """The oracle restatement of the same step on the host cores ("port"), bounded to ~budget_s of CPU work."""
+def cpu_baseline(cfgd, host_data, global_step, budget_s=25.0):
+    """The oracle restatement of the same step on the host cores ("port"), bounded to ~budget_s of CPU work. The ONLY
+    place in this file that touches oracle/ (test infrastructure): a reported CPU baseline, never the thing measured."""
+    from oracle import cgn_oracle as O
+    ocfg = O.OracleConfig(**cfgd)
     torch.manual_seed(1234)
     model = O.CGN(ocfg, O.synthetic_word_embed(ocfg))
     opts = O.make_optimizers(model)
@@ -104,7 +107,7 @@ def main():
     from ldrs_amd.model.cgn import Controlled_Generation_Sentence
     from ldrs_amd.utils.config import Config
     from ldrs_amd.utils.functional import kld_coef, temp_coef
-    from oracle import cgn_oracle as O  # synthetic inputs + the cpu_baseline leg only
+    from ldrs_amd.utils import synthetic
 
     if args.force_dp and args.gpus == 1 and "RANK" not in os.environ:
         os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29511")
@@ -123,17 +126,16 @@ def main():
 
     cfgd, BATCH, SEQ = WORKLOADS[args.workload]
     cfg = make_config(Config, cfgd)
-    ocfg = O.OracleConfig(**cfgd)
     if args.workload != "cfg2":
         args.no_cpu_baseline = True  # the CPU oracle needs minutes per step at this size
     ops.set_compute(args.compute)
     torch.manual_seed(1234)  # identical replicas on every rank
-    model = Controlled_Generation_Sentence(cfg, O.synthetic_word_embed(ocfg)).cuda()
+    model = Controlled_Generation_Sentence(cfg, synthetic.synthetic_word_embed(cfg)).cuda()
     if world > 1 or args.force_dp:
         parallel.attach(model, force=args.force_dp)
     eng = model.step_engine()
     opts = dict(disc=eng.new_optimizer("disc"), enc=eng.new_optimizer("enc"), gen=eng.new_optimizer("gen"))
-    data, host_data = device_data(O, ocfg, BATCH, SEQ, 1234 + rank, dev)
+    data, host_data = device_data(synthetic, cfg, BATCH, SEQ, 1234 + rank, dev)
     global_step = 5000
     kc, tau = kld_coef(global_step), temp_coef(global_step)
 
@@ -227,7 +229,7 @@ def main():
                                    "graph replays" if graph_timing else "inside the timed region")},
         }
         if world == 1 and not args.no_cpu_baseline and not dp:
-            out["cpu_baseline"] = cpu_baseline(O, ocfg, host_data, global_step)
+            out["cpu_baseline"] = cpu_baseline(cfgd, host_data, global_step)
         print(json.dumps(out), flush=True)
 
     def check_lstm():

@@ -76,3 +76,44 @@ class SyntheticDataHandler:
         X = rng.randint(0, self.config.word_vocab_size - 3, size=(n, self.L)).tolist()
         c = torch.from_numpy(rng.randint(0, 2, size=(n, 1)).astype(np.float32))
         return X, c
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Seeded tensors of one benchmark / parity batch. The CPU oracle (test infrastructure) has generators of
+# its own that draw the same streams; bench.py's measured leg uses THESE, so that nothing measured imports the oracle.
+# ------------------------------------------------------------------------------------------------------------------
+def synthetic_word_embed(config, seed=1234):
+    """Frozen word embedding ~ U(-1,1) * 0.25, [V, E] float32 numpy."""
+    g = torch.Generator().manual_seed(seed)
+    return ((torch.rand(config.word_vocab_size, config.word_embed_size, generator=g) * 2 - 1) * 0.25).numpy()
+
+
+def synthetic_batch(config, B, L, seed=1234):
+    """Fixed-length sentences laid out as utils/batch_loader.py:271-316 does (enc_* reversed, dec = [go]+s,
+    target = s+[end], special tokens = the last vocabulary indices) plus the step's random draws and the two
+    discriminator batches, as CPU tensors."""
+    g = torch.Generator().manual_seed(seed)
+    V = config.word_vocab_size
+    s = torch.randint(0, V - 3, (B, L), generator=g)
+    chars = torch.randint(0, config.char_vocab_size, (B, L, config.max_word_len), generator=g)
+    go, end = V - 2, V - 1
+    out = dict(
+        enc_word=torch.flip(s, dims=[1]).contiguous(), enc_char=torch.flip(chars, dims=[1]).contiguous(),
+        dec_word=torch.cat([torch.full((B, 1), go, dtype=torch.int64), s], 1),
+        target=torch.cat([s, torch.full((B, 1), end, dtype=torch.int64)], 1),
+        eps=torch.randn(B, config.latent_variable_size, generator=g),
+        eps_recon=torch.randn(B, config.latent_variable_size, generator=g),
+        c_uniform=torch.rand(B, generator=g),
+        x_labelled=torch.randint(0, V - 3, (B, L), generator=g),
+        y_labelled=torch.randint(0, 2, (B,), generator=g),
+        x_generated=torch.randint(0, V - 3, (B, L), generator=g),
+        c_generated=torch.randint(0, 2, (B,), generator=g),
+    )
+    C = getattr(config, "c_size", 1)
+    if C > 1:  # multi-attribute extension: one label / code / uniform column per attribute
+        for k, draw in (("c_uniform", lambda: torch.rand(B, generator=g)),
+                        ("y_labelled", lambda: torch.randint(0, 2, (B,), generator=g)),
+                        ("c_generated", lambda: torch.randint(0, 2, (B,), generator=g))):
+            out[k] = torch.stack([out[k]] + [draw() for _ in range(C - 1)], 1)
+    return out
+

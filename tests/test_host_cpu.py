@@ -152,3 +152,24 @@ def test_gemm_planner_host_only():
     assert rc == _lib.CGN_ERR_INVALID_ARG
     rc, (tile, sk, _, _) = _plan(256, 256, 4096, force_tile=64, force_splitk=4)
     assert rc == 0 and tile == 64 and sk == 4
+
+
+def test_package_synthetic_inputs_equal_the_oracles():
+    """bench.py's measured leg draws its inputs with ldrs_amd.utils.synthetic (no oracle import on that leg); the oracle's
+    own generators (used by the parity tests) draw the same streams."""
+    import numpy as np
+    import torch
+    import ldrs_amd  # noqa: F401
+    from ldrs_amd.utils import synthetic
+    from ldrs_amd.utils.config import Config
+    from oracle import cgn_oracle as O
+    for c_size in (1, 2):
+        kw = dict(word_embed_size=12, kernels=((1, 3), (2, 5)), encoder_rnn_size=16, latent_variable_size=6,
+                  decoder_rnn_size=20, sentiment_kernel_size=(3, 4), sentiment_kernel_num=5, c_size=c_size)
+        cfg = Config(7, 5, 50, 20, 5e-5, 7.9, 0.1, 0.1, 1.0, **kw)
+        ocfg = O.OracleConfig(max_word_len=7, max_seq_len=6, word_vocab_size=50, char_vocab_size=20, **kw)
+        a, b = synthetic.synthetic_batch(cfg, 4, 5, seed=9), O.synthetic_batch(ocfg, 4, 5, seed=9)
+        assert sorted(a) == sorted(b)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+        np.testing.assert_array_equal(synthetic.synthetic_word_embed(cfg), O.synthetic_word_embed(ocfg))
