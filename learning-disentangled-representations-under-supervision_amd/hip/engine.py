@@ -118,7 +118,7 @@ def highway_fwd(x, layers):
         pre = _new((N, 3 * Sp), x.device)
         # compute="f32" also in the bf16 mode: the nonlinear branch feeds a ReLU whose gates flip under bf16 operand
         # rounding, and the gradients below the highway (char-TDNN, char embedding) amplify the perturbation of the
-        # other two branches: measured against the oracle (tools/bf16_sensitivity.py, tests/test_step_gpu.py) they go
+        # other two branches: measured against the oracle (tests/diag_bf16_sensitivity.py, tests/test_step_gpu.py) they go
         # 3e-2 with all three branches in bf16, 1.6e-2 with the ReLU branch alone in fp32, 6e-3 with all three in fp32
         if p.get("wcat") is not None:
             ops.gemm(x, p["wcat"].t(), pre, bias0=p["bcat"], compute="f32")

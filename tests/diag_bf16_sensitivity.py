@@ -1,8 +1,9 @@
-"""Diagnostic: which products of the step carry the bf16 mode's gradient error? Runs the 'mid' parity case in bf16 mode
+"""Diagnostic (test infrastructure, run by hand: python tests/diag_bf16_sensitivity.py on a GPU box; not collected by
+pytest): which products of the step carry the bf16 mode's gradient error? Runs the 'mid' parity case in bf16 mode
 with the products issued from chosen host functions forced back to fp32 and prints the worst gradient errors."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 import ldrs_amd  # noqa
 from ldrs_amd.hip import ops

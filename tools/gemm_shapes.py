@@ -9,16 +9,15 @@ from ldrs_amd.hip import ops
 from ldrs_amd.model.cgn import Controlled_Generation_Sentence
 from ldrs_amd.utils.config import Config
 from ldrs_amd.utils.functional import kld_coef, temp_coef
-from oracle import cgn_oracle as O
+from ldrs_amd.utils import synthetic
 
 dev = torch.device("cuda", 0)
 cfg = bench.make_config(Config)
-ocfg = O.OracleConfig(**bench.CFG2)
 torch.manual_seed(1234)
-model = Controlled_Generation_Sentence(cfg, O.synthetic_word_embed(ocfg)).cuda()
+model = Controlled_Generation_Sentence(cfg, synthetic.synthetic_word_embed(cfg)).cuda()
 eng = model.step_engine()
 opts = dict(disc=eng.new_optimizer("disc"), enc=eng.new_optimizer("enc"), gen=eng.new_optimizer("gen"))
-data, _ = bench.device_data(O, ocfg, bench.BATCH, bench.SEQ, 1234, dev)
+data, _ = bench.device_data(synthetic, cfg, bench.BATCH, bench.SEQ, 1234, dev)
 zl = "--z-loss" in sys.argv
 
 def step():

@@ -7,13 +7,12 @@ import ldrs_amd  # noqa
 from ldrs_amd.hip.sampler import BeamSampler
 from ldrs_amd.model.cgn import Controlled_Generation_Sentence
 from ldrs_amd.utils.config import Config
-from oracle import cgn_oracle as O
+from ldrs_amd.utils import synthetic
 
 dev = torch.device("cuda", 0)
 cfg = bench.make_config(Config)
-ocfg = O.OracleConfig(**bench.CFG2)
 torch.manual_seed(1234)
-model = Controlled_Generation_Sentence(cfg, O.synthetic_word_embed(ocfg)).cuda()
+model = Controlled_Generation_Sentence(cfg, synthetic.synthetic_word_embed(cfg)).cuda()
 eng = model.step_engine()
 V = cfg.word_vocab_size
 for S, K in ((10, 10), (64, 10), (64, 1)):
