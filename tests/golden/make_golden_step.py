@@ -45,7 +45,17 @@ import numpy as np
 import torch
 
 REF = "/root/reference"
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_step.npz")
+HERE = os.path.dirname(os.path.abspath(__file__))
+# name -> (file, Config positional args, dims that config.py hard-codes, batch size): "tiny" = 16-byte friendly sizes,
+# "odd" = every row stride unaligned (E = 33), hidden sizes that are not multiples of 16, four TDNN widths
+CASES = {
+    "tiny": ("reference_step.npz", dict(max_word_len=7, max_seq_len=5, word_vocab_size=50, char_vocab_size=20),
+             dict(word_embed_size=12, encoder_rnn_size=16, latent_variable_size=6, decoder_rnn_size=20,
+                  kernels=[(1, 3), (2, 5), (3, 4)], sentiment_kernel_num=6), 4),
+    "odd": ("reference_step_odd.npz", dict(max_word_len=8, max_seq_len=8, word_vocab_size=101, char_vocab_size=31),
+            dict(word_embed_size=33, encoder_rnn_size=20, latent_variable_size=10, decoder_rnn_size=28,
+                 kernels=[(1, 5), (2, 7), (3, 6), (6, 13)], sentiment_kernel_num=9), 7),
+}
 
 
 def exec_module(relpath, modname, package, subs=(), py2=True):
@@ -102,18 +112,24 @@ def main():
                                     ("Beam(beam_size, batch_loader, cuda=True)", "Beam(beam_size, batch_loader, cuda=False)"),
                                     ("active_idx = t.cuda.LongTensor(", "active_idx = t.LongTensor(")])
 
-    cfg = Config(max_word_len=7, max_seq_len=5, word_vocab_size=50, char_vocab_size=20, learning_rate=5e-5,
-                 lambda_c=7.9, lambda_z=0.1, lambda_u=0.1, beta=1.0)
+    for case in (sys.argv[1:] or list(CASES)):
+        generate(cgn_mod, Config, *CASES[case])
+
+
+def generate(cgn_mod, Config, fname, pos, dims, B):
+    OUT = os.path.join(HERE, fname)
+    cfg = Config(learning_rate=5e-5, lambda_c=7.9, lambda_z=0.1, lambda_u=0.1, beta=1.0, **pos)
     # shrink the hard-coded dims (config.py:14-31) so the fixture stays small
-    cfg.word_embed_size, cfg.encoder_rnn_size, cfg.latent_variable_size = 12, 16, 6
-    cfg.decoder_rnn_size, cfg.decoder_num_layers = 20, 2
-    cfg.kernels = [(1, 3), (2, 5), (3, 4)]
-    cfg.sum_depth = 12
-    cfg.sentiment_kernel_size, cfg.sentiment_kernel_num = [3, 4, 5], 6
+    for k, v in dims.items():
+        setattr(cfg, k, v)
+    cfg.decoder_num_layers = 2
+    cfg.sum_depth = sum(od for _, od in cfg.kernels)
+    cfg.sentiment_kernel_size = [3, 4, 5]
     out = {"dims": np.array([cfg.max_word_len, cfg.max_seq_len, cfg.word_vocab_size, cfg.char_vocab_size,
                              cfg.word_embed_size, cfg.encoder_rnn_size, cfg.latent_variable_size, cfg.decoder_rnn_size,
                              cfg.sentiment_kernel_num, cfg.char_embed_size]),
-           "sentiment_dropout": np.array(cfg.sentiment_dropout), "learning_rate": np.array(cfg.learning_rate)}
+           "sentiment_dropout": np.array(cfg.sentiment_dropout), "learning_rate": np.array(cfg.learning_rate),
+           "kernels": np.array(cfg.kernels)}
 
     g = torch.Generator().manual_seed(20171110)
     V, E = cfg.word_vocab_size, cfg.word_embed_size
@@ -141,7 +157,7 @@ def main():
         lambda m, i, o: masks.append((i[0].detach().clone(), o.detach().clone())) if m.training else None)
     p_keep = 1.0 - cfg.sentiment_dropout
 
-    B, L = 4, cfg.max_seq_len - 1
+    L = cfg.max_seq_len - 1
     for it in range(2):
         tag = "it%d/" % it
         calc_z = it == 1  # iteration 0 as train_functions.py runs it (calc_z_loss=False), iteration 1 with the z pass
@@ -230,13 +246,20 @@ def main():
     S_, K_, NB_ = 3, 4, 2
     seed_zc = torch.randn(S_, cfg.latent_variable_size + 1, generator=g)
     seed_zc[:, -1] = (seed_zc[:, -1] > 0).float()
-    codes, scores = cgn.sample_from_generator(Vocab(), cfg.max_seq_len, seed_zc.clone(), False, beam_size=K_, n_best=NB_,
-                                              samples=S_)
-    codes = np.asarray([[[int(w) for w in step] for step in sent] for sent in codes])  # [S, T, n_best]
-    assert codes.shape == (S_, cfg.max_seq_len, NB_), codes.shape
-    out["sampler/seed"], out["sampler/codes"] = seed_zc.numpy(), codes
-    out["sampler/scores"] = np.stack([sc.detach().numpy() for sc in scores])
-    out["sampler/params"] = np.array([S_, K_, NB_, cfg.max_seq_len])
+    try:
+        codes, scores = cgn.sample_from_generator(Vocab(), cfg.max_seq_len, seed_zc.clone(), False, beam_size=K_,
+                                                  n_best=NB_, samples=S_)
+    except RuntimeError as e:
+        # a sentence reached <eos>: the reference then tiles the seeds for the ORIGINAL number of sentences against
+        # the compacted batch (generator.py:30-32) and its own view() fails - no sampler vectors for this case
+        print("  sampler: the reference raised after a sentence finished (%s); not recorded" % str(e)[:60])
+        codes = None
+    if codes is not None:
+        codes = np.asarray([[[int(w) for w in step] for step in sent] for sent in codes])  # [S, T, n_best]
+        assert codes.shape == (S_, cfg.max_seq_len, NB_), codes.shape
+        out["sampler/seed"], out["sampler/codes"] = seed_zc.numpy(), codes
+        out["sampler/scores"] = np.stack([sc.detach().numpy() for sc in scores])
+        out["sampler/params"] = np.array([S_, K_, NB_, cfg.max_seq_len])
 
     # ---- initial VAE pre-training (cgn.py:105-132, 621-674; main.py:97-118): a FRESH model from the same initial
     # state, two training steps (one Adam over every learnable parameter) and one validation step
