@@ -256,6 +256,7 @@ def main():
     watchdog = None
     lstm_note = ""
     if dp and want_graph:
+        initial = {k: a.p.clone() for k, a in eng.arenas.items()}  # to start over if a launch times out (see below)
         eager_result = timed(eager_step, True)
         eager_prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
         torch.cuda.synchronize()
@@ -271,6 +272,13 @@ def main():
                   file=sys.stderr, flush=True)
             ops.LSTM_PERSISTENT = False
             ops.clear_lstm_sticky_timeouts()
+            for k, a in eng.arenas.items():  # the timed-out steps trained on invalid activations: start over
+                a.p.copy_(initial[k])
+            for st in opts.values():
+                st.m.zero_()
+                st.v.zero_()
+                st.step = 0
+                st.sync_device_step()
             lstm_note = ", per-timestep LSTM kernels (a persistent launch timed out beside the collectives)"
             eager_result = timed(eager_step, True)
             eager_prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
