@@ -23,7 +23,12 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static inline int cgn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+// ceil(a / b) as an int, SATURATING at INT_MAX (block counts derived from it are clamped by their callers; tile counts
+// cannot reach it: every GEMM dimension is checked < 2^30)
+static inline int cgn_cdiv(long a, long b) {
+    const long q = (a + b - 1) / b;
+    return q > 2147483647L ? 2147483647 : (int)q;
+}
 
 __device__ __forceinline__ float cgn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 

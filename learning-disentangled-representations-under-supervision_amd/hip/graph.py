@@ -80,14 +80,22 @@ class GraphedWakeSleep:
         eng.overlap, eng.dynamic = overlap, True
         try:
             self.stream.wait_stream(torch.cuda.current_stream(eng.dev))
-            with torch.cuda.stream(self.stream):
-                # warm-up on the capture stream and its side streams: creates the per-stream workspaces and loads every
-                # kernel before capture (allocation and module loading are illegal while capturing)
-                eng.set_step_scalars(warmup_kld, warmup_tau, self.NT, self.B, self._slot())
-                self._run()
-                self._bump_host_steps()
-            torch.cuda.current_stream(eng.dev).wait_stream(self.stream)
-            torch.cuda.synchronize(eng.dev)
+            # The warm-up is a REAL training step issued over the capture stream and its side streams: its temporaries
+            # are read across streams, so they are kept alive (ops.KEEP) until the device has drained, exactly like the
+            # captured step's (torch's per-stream caching allocator would otherwise recycle a block under a side-stream
+            # reader).
+            ops.KEEP = []
+            try:
+                with torch.cuda.stream(self.stream):
+                    # warm-up on the capture stream and its side streams: creates the per-stream workspaces and loads
+                    # every kernel before capture (allocation and module loading are illegal while capturing)
+                    eng.set_step_scalars(warmup_kld, warmup_tau, self.NT, self.B, self._slot())
+                    self._run()
+                    self._bump_host_steps()
+                torch.cuda.current_stream(eng.dev).wait_stream(self.stream)
+                torch.cuda.synchronize(eng.dev)
+            finally:
+                ops.KEEP = None
             ops.KEEP = []
             try:
                 if eng.dp:
@@ -142,10 +150,13 @@ class GraphedWakeSleep:
         if data is not None:
             self.load(data)
         eng.set_step_scalars(kld_coeff, temperature, self.NT, self.B, self._slot())
-        for g, actions in self.segments:
+        for i, (g, actions) in enumerate(self.segments):
+            self.progress = (self.calls, i, "replay")
             g.replay()
             for kind, group in actions:
+                self.progress = (self.calls, i, kind + " " + group)
                 eng.do_comm(kind, group)
+        self.progress = (self.calls, len(self.segments), "done")
         self._bump_host_steps()
         d_losses, c, eg = self.out
         ce, kld, z_loss, c_loss = eg[:4]

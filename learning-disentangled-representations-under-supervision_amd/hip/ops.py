@@ -79,12 +79,20 @@ def alloc(shape, dev, dtype=torch.float32):
 
 
 def _span_ok(t, base_off, axes_extents):
-    """Host-side bounds check: the largest element offset reached must lie inside the tensor's storage."""
+    """Host-side bounds check: the largest element offset reached must lie inside the tensor's storage. Where the
+    library may read an axis in 16-byte quads although its extent is not a multiple of 4 (csrc/gemm.hip axis_vec_ok:
+    unit stride, plain axes, the other axis' stride covers the rounded-up extent) the extent counts rounded up: the
+    last row's quad must lie inside the storage too."""
     hi = base_off
-    for ax, n in axes_extents:
+    quads = t.data_ptr() % 16 == 0  # the library never issues 16-byte loads from an unaligned base
+    for j, (ax, n) in enumerate(axes_extents):
         if n <= 0:
             return True
         i = n - 1
+        other = axes_extents[1 - j][0] if len(axes_extents) == 2 else None
+        if (quads and n % 4 and ax.stride == 1 and ax.rpg == 0 and other is not None and other.rpg == 0
+                and other.stride % 4 == 0 and other.stride >= pad4(n)):
+            i = pad4(n) - 1
         if ax.rpg > 0:
             g = i // ax.rpg
             last = g * ax.gs + (i % ax.rpg) * ax.stride
@@ -575,6 +583,22 @@ def lstm_sticky_timeouts():
     means some persistent launch since start-up ran out of a bounded wait and produced invalid results (a co-scheduled
     kernel kept its workgroups from becoming resident together). One device read per buffer; synchronises."""
     return sum(int(ws[-32].item() != 0) for ws in _lstm_sync.values())
+
+
+class LstmTimeoutError(RuntimeError):
+    pass
+
+
+def raise_on_lstm_timeout():
+    """Product-path check (train_functions.py, the step closures' logging points, the sampler, checkpoint save): a
+    persistent LSTM launch whose bounded wait ran out has produced invalid activations, and every step since then has
+    trained on them. Raises LstmTimeoutError; the caller decides (ops.LSTM_PERSISTENT = False takes the per-timestep
+    kernels). Synchronises (one word per scratch buffer): call it where the host already waits for the device."""
+    if lstm_sticky_timeouts():
+        raise LstmTimeoutError(
+            "a persistent LSTM launch did not get its workgroups resident together and ran out of a bounded wait: "
+            "activations since then are invalid. Reload the last checkpoint and rerun with CGN_LSTM_PERSISTENT=0 "
+            "(or set ldrs_amd.hip.ops.LSTM_PERSISTENT = False).")
 
 
 def clear_lstm_sticky_timeouts():

@@ -58,11 +58,14 @@ class BeamSampler:
     """use_graph: capture the token step (first / subsequent) into two hipGraphs per (S, K) and replay them; the
     eager form issues the same kernels one by one."""
 
-    _cache = {}
-
     def __init__(self, eng, use_graph=True):
         self.eng = eng
         self.use_graph = use_graph
+        # Decode states (static buffers + captured token-step graphs, which hold raw pointers into THIS engine's
+        # parameter arenas) are kept on the engine object: they die with the arenas they point into, and a new engine
+        # (model.cuda() / set_data_parallel() build one) can never pick up another engine's graphs.
+        if not hasattr(eng, "_decode_states"):
+            eng._decode_states = {}
 
     def _token_step(self, st, first, eos, pad):
         """One decode step over all S*K rows, reading and updating the static state in `st`."""
@@ -136,10 +139,12 @@ class BeamSampler:
         R = S * K
         if seed.shape[1] != cfg.latent_variable_size + cfg.c_size:
             raise ValueError("seed must be [S, Z + C]")
-        key = (id(eng), S, K)
-        st = BeamSampler._cache.get(key)
+        key = (S, K)
+        st = eng._decode_states.get(key)
         if st is None:
-            st = BeamSampler._cache[key] = _DecodeState(eng, S, K)
+            if len(eng._decode_states) >= 4:  # bounded: each state holds an [S*K, V] logits buffer and two graphs
+                eng._decode_states.pop(next(iter(eng._decode_states)))
+            st = eng._decode_states[key] = _DecodeState(eng, S, K)
         graphed = self.use_graph and ops.KEEP is None  # never nest inside another capture
         if graphed and (st.graphs is None or st.tokens_key != (go, eos, pad)):
             self._build_graphs(st, go, eos, pad)
@@ -159,6 +164,7 @@ class BeamSampler:
             hist_org[i].copy_(st.org_out, non_blocking=True)
             if bool(st.done.all().item()):  # cgn.py:840-841 (host check per token, as in the reference)
                 break
+        ops.raise_on_lstm_timeout()  # the loop has just synchronised: one more word read costs nothing
 
         # (4) package everything up, cgn.py:872-882: walk the back-pointers (Beam.get_hyp, beam_search.py:121-132)
         tok_h, org_h, len_h = hist_tok.cpu(), hist_org.cpu(), st.length.cpu().tolist()

@@ -25,6 +25,13 @@ def _new(shape, dev, dtype=torch.float32):
     return ops.alloc(shape, dev, dtype)
 
 
+def _cap_sel(capture, key, t):
+    """Parity-test aid: which ReLU gates were open / which window won each max-over-time in THIS pass (the step is
+    piecewise smooth; tests/test_step_gpu.py compares gradients on the region the fp32 pass actually took)."""
+    if capture is not None:
+        capture.setdefault("sel", {})[key] = t.clone()
+
+
 class CGNStep:
     def __init__(self, model, allreduce=None, world_size=1, force_dp=False):
         """model: Controlled_Generation_Sentence on a HIP device. allreduce: parallel.BucketedAllReduce-like object
@@ -119,6 +126,23 @@ class CGNStep:
                 ev.record(self._side_streams[k])
                 torch.cuda.current_stream(self.dev).wait_event(ev)
                 self._dirty.discard(k)
+
+    @contextlib.contextmanager
+    def keepalive(self):
+        """With `overlap` on, temporaries allocated on one stream are read by kernels on another; torch's caching
+        allocator hands a block back to its own stream's pool the moment the Python reference drops, without knowing
+        about the other stream. So while a step with side streams is being ISSUED every temporary is kept (ops.KEEP),
+        and released only after the side streams have been joined into the current stream (from then on any reuse is
+        ordered behind every reader). A surrounding KEEP (graph capture, hip/graph.py) is left alone."""
+        if not self.overlap or ops.KEEP is not None:
+            yield
+            return
+        ops.KEEP = []
+        try:
+            yield
+            self.join(0, 1)
+        finally:
+            ops.KEEP = None
 
     def _dyn(self, lo=0):
         return self.dyn[lo:] if self.dynamic else None
@@ -250,6 +274,7 @@ class CGNStep:
             stats_all = []
             for i, ((emb, (B, L)), y, mask, w_ce, w_ent) in enumerate(passes):
                 feat, arg = self._disc_features(emb, B, L, a)
+                _cap_sel(capture, "disc_%s%d/conv" % ("lg"[i], a), arg)
                 logits, dlog, stats = _new((B, 2), self.dev), _new((B, 2), self.dev), _new((2,), self.dev)
                 ops.disc_head(feat, W, b, logits, mask=mask, y=y, w_ce=w_ce, w_ent=w_ent, dlogits=dlog, stats=stats)
                 stats_all.append(stats)
@@ -354,6 +379,10 @@ class CGNStep:
         encoder/generator step. opts: dict(disc, enc, gen); d: dict of device tensors (x_labelled, y_labelled,
         x_generated, c_generated, mask_labelled, mask_generated, enc_word, enc_char, dec_word, target, c_uniform, eps).
         With `overlap` the discriminator step and c inference run beside the encoder forward (they only meet at c)."""
+        with self.keepalive():
+            return self._wake_sleep(opts, d, kld_coeff, temperature, calc_z_loss)
+
+    def _wake_sleep(self, opts, d, kld_coeff, temperature, calc_z_loss):
         if self.dp:
             # Data-parallel schedule (SURVEY.md §8e), four segments with three reductions between them:
             #   [disc gradients || embedding + encoder forward] -> reduce disc (1.5 MB) -> [disc Adam, c inference,
@@ -392,6 +421,12 @@ class CGNStep:
         enc_word [B,L], enc_char [B,L,W], dec_word [B,T], target [B,T] int64; c_target [B] or [B,C] float;
         eps [B,Z] (the randn of cgn.py:96); gen_drop_mask None or [B,T,E] (explicit, scaled word-dropout mask).
         Returns (cross_entropy, kld, z_loss, c_loss, total_encoder_loss, total_generator_loss) device scalars."""
+        with self.keepalive():
+            return self._enc_gen_train(opts, enc_word, enc_char, dec_word, target, c_target, eps, kld_coeff,
+                                       temperature, gen_drop_mask, calc_z_loss, capture, train, use_disc, joint)
+
+    def _enc_gen_train(self, opts, enc_word, enc_char, dec_word, target, c_target, eps, kld_coeff, temperature,
+                       gen_drop_mask, calc_z_loss, capture, train, use_disc, joint):
         cfg, P, G, dev = self.cfg, self.P, self.G, self.dev
         B, L = enc_word.shape
         T = dec_word.shape[1]
@@ -412,8 +447,11 @@ class CGNStep:
         tk = self._tdnn_kernels(P)
         tfeat, tsaved = engine.tdnn_fwd(enc_char.reshape(N, Wl), P["embedding.char_embed.weight"], tk)
         ops.copy2d(tfeat, enc_in[:, E:])
+        _cap_sel(capture, "enc/tdnn", tsaved["arg"])
         # ---- encode_for_z (cgn.py:83-103) + KLD (:1076) + [z,c] (:1080) ------------------------------------------
         es = self._encoder_fwd(enc_in, B, L)
+        for l, (_, pre) in enumerate(es["hw_saved"]):
+            _cap_sel(capture, "enc/hw%d" % l, pre[:, :Din] > 0)
         mulv = es["mulv"]
         zc, std, kld = _new((B, Z + C), dev), _new((B, Z), dev), _new((1,), dev)
         if callable(c_target):
@@ -460,6 +498,7 @@ class CGNStep:
             for a in range(C):
                 cw, cb = self._conv_params(P, a)
                 feat_d, arg_d = engine.textcnn_features_fwd(out_emb, B, L, E, T * E, cw, cb)  # rows t < L per sentence
+                _cap_sel(capture, "soft%d/conv" % a, arg_d)
                 fcw, fcb = self._fc_params(P, a)
                 logits2, dlog2, stats2 = _new((B, 2), dev), _new((B, 2), dev), _new((2,), dev)
                 y_c = _new((B,), dev, torch.int64)
@@ -482,6 +521,8 @@ class CGNStep:
             ops.copy3d(out_emb.view(B, T, E)[:, :L], enc_in2.unflatten(0, (B, L))[:, :, :E])
             ops.copy2d(tfeat, enc_in2[:, E:])
             es2 = self._encoder_fwd(enc_in2, B, L)
+            for l, (_, pre) in enumerate(es2["hw_saved"]):
+                _cap_sel(capture, "recon/hw%d" % l, pre[:, :Din] > 0)
             dmulv2 = _new((B, 2 * Z), dev)
             ops.mahalanobis(mulv, es2["mulv"], cfg.lambda_z, z_loss, dmulv2)
             if train:

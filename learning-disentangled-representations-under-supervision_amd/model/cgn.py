@@ -29,29 +29,24 @@ def _to_device_long(arr, use_cuda):
 class Controlled_Generation_Sentence(nn.Module):
 
     def __init__(self, config, embedding_path):
-        super(Controlled_Generation_Sentence, self).__init__()
-
+        super().__init__()
         self.config = config
-        self.embedding = Embedding(self.config, embedding_path)
-        self.embedding_param_autograd = [1 if param.requires_grad else 0 for param in self.embedding.parameters()]
-
-        self.encoder = Encoder(self.config)
-        self.encoder_param_autograd = [1 if param.requires_grad else 0 for param in self.encoder.parameters()]
-
-        self.e2mu = hnn.Linear(self.config.encoder_rnn_size * 2, self.config.latent_variable_size)
-        self.e2logvar = hnn.Linear(self.config.encoder_rnn_size * 2, self.config.latent_variable_size)
-
-        self.generator = Generator(self.config)
-        self.generator_param_autograd = [1 if param.requires_grad else 0 for param in self.generator.parameters()]
-
-        self.sentiment_discriminator = Sentiment_CNN(self.config)
-        self.sentiment_discriminator_autograd = [1 if param.requires_grad else 0
-                                                 for param in self.sentiment_discriminator.parameters()]
+        He, Z = config.encoder_rnn_size, config.latent_variable_size
+        # sub-module names are the reference's (cgn.py:26-44): they ARE the state_dict keys
+        self.embedding = Embedding(config, embedding_path)
+        self.encoder = Encoder(config)
+        self.e2mu = hnn.Linear(2 * He, Z)
+        self.e2logvar = hnn.Linear(2 * He, Z)
+        self.generator = Generator(config)
+        self.sentiment_discriminator = Sentiment_CNN(config)
         # Multi-attribute extension (BASELINE.json configs[4]: c = sentiment + tense, one text-CNN per attribute):
         # attribute 0 keeps the reference's module; config.c_size = 1 (the reference) leaves this list empty and the
         # state_dict unchanged.
         self.attribute_discriminators = nn.ModuleList(
-            [Sentiment_CNN(self.config) for _ in range(getattr(self.config, "c_size", 1) - 1)])
+            [Sentiment_CNN(config) for _ in range(getattr(config, "c_size", 1) - 1)])
+        # which parameters were trainable at construction (the frozen word table is not): the *_mode() switches below
+        # only ever re-enable these (the reference keeps 0/1 lists per sub-module for the same purpose, cgn.py:30-44)
+        self._born_trainable = {id(p) for p in self.parameters() if p.requires_grad}
 
         # kld_coef variant: True reproduces the reference under its own interpreter (Python 2 floor division)
         self.kld_py2_floor = True
@@ -80,9 +75,8 @@ class Controlled_Generation_Sentence(nn.Module):
 
     def compute_mahalabonis(self, mu1, mu2, std1, std2):
         """cgn.py:47-57 (diagnostic helper; the training step uses the fused kernel cgn_mahalanobis_f32)."""
-        std = (std1 + std2) / 2
-        delta_mu = mu1 - mu2
-        return t.sqrt(t.sum(delta_mu * t.reciprocal(std) * delta_mu, 1))
+        d = mu1 - mu2
+        return (d * d / (0.5 * (std1 + std2))).sum(1).sqrt()
 
     def encode_for_z(self, encoder_input, batch_size, use_cuda, eps=None):
         """cgn.py:83-103. `eps` optionally replaces the t.randn draw of :96. Returns (z, std, logvar, mu)."""
@@ -187,72 +181,61 @@ class Controlled_Generation_Sentence(nn.Module):
     # mode switches (cgn.py:346-395, 688-745) — kept for API compatibility; the fused step decides what to update from
     # the closure being called, exactly as the reference's optimizers do from their parameter lists
     # ------------------------------------------------------------------------------------------------------------
+    def _set_phase(self, train_disc, train_enc_gen):
+        """requires_grad + train()/eval() of the three parts in one place (cgn.py:346-395 spell out the four cases)."""
+        self.discriminator_mode(train_mode=train_disc)
+        self.encoder_mode(train_mode=train_enc_gen)
+        self.generator_mode(train_mode=train_enc_gen)
+        for d in self._discriminators():
+            d.train(train_disc)
+        self.encoder.train(train_enc_gen)
+        self.generator.train(train_enc_gen)
+
     def prep_disc_validation(self):
-        self.discriminator_mode(train_mode=False)
-        self.encoder_mode(train_mode=False)
-        self.generator_mode(train_mode=False)
-        self.sentiment_discriminator.eval()
-        self.encoder.eval()
-        self.generator.eval()
+        self._set_phase(False, False)
 
     def prep_disc_training(self):
-        self.discriminator_mode(train_mode=True)
-        self.encoder_mode(train_mode=False)
-        self.generator_mode(train_mode=False)
-        self.sentiment_discriminator.train()
-        self.encoder.eval()
-        self.generator.eval()
+        self._set_phase(True, False)
 
     def prep_enc_gen_validation(self):
-        self.encoder_mode(train_mode=False)
-        self.generator_mode(train_mode=False)
-        self.discriminator_mode(train_mode=False)
-        self.encoder.eval()
-        self.generator.eval()
-        self.sentiment_discriminator.eval()
+        self._set_phase(False, False)
 
     def prep_enc_gen_training(self):
-        self.discriminator_mode(train_mode=False)
-        self.sentiment_discriminator.eval()
-        self.encoder_mode(train_mode=True)
-        self.generator_mode(train_mode=True)
-        self.encoder.train()
-        self.generator.train()
+        self._set_phase(False, True)
+
+    def _discriminators(self):
+        return [self.sentiment_discriminator] + list(self.attribute_discriminators)
+
+    @staticmethod
+    def _trainable(*modules):
+        return [p for m in modules for p in m.parameters() if p.requires_grad]
 
     def encoder_params(self):
-        enc_params = [p for p in self.encoder.parameters() if p.requires_grad]
-        enc_params.extend([p for p in self.embedding.parameters() if p.requires_grad])
-        enc_params.extend([p for p in self.e2mu.parameters() if p.requires_grad])
-        enc_params.extend([p for p in self.e2logvar.parameters() if p.requires_grad])
-        return enc_params
+        """cgn.py:676-683: the encoder optimizer's parameters, in the reference's order."""
+        return self._trainable(self.encoder, self.embedding, self.e2mu, self.e2logvar)
 
     def generator_params(self):
-        return [p for p in self.generator.parameters() if p.requires_grad]
+        return self._trainable(self.generator)
 
     def sentiment_discriminator_parameters(self):
-        return [p for p in self.sentiment_discriminator.parameters() if p.requires_grad] + \
-               [p for p in self.attribute_discriminators.parameters() if p.requires_grad]
+        return self._trainable(*self._discriminators())
 
     def learnable_parameters(self):
-        return [p for p in self.parameters() if p.requires_grad]
+        return self._trainable(self)
+
+    def _switch(self, modules, on):
+        for m in modules:
+            for p in m.parameters():
+                p.requires_grad = bool(on) and id(p) in self._born_trainable
 
     def encoder_mode(self, train_mode=False):
-        for i, param in enumerate(self.encoder.parameters()):
-            param.requires_grad = bool(train_mode and self.encoder_param_autograd[i])
-        for i, param in enumerate(self.embedding.parameters()):
-            param.requires_grad = bool(train_mode and self.embedding_param_autograd[i])
-        for param in list(self.e2mu.parameters()) + list(self.e2logvar.parameters()):
-            param.requires_grad = bool(train_mode)
+        self._switch((self.encoder, self.embedding, self.e2mu, self.e2logvar), train_mode)
 
     def discriminator_mode(self, train_mode=True):
-        for i, param in enumerate(self.sentiment_discriminator.parameters()):
-            param.requires_grad = bool(train_mode and self.sentiment_discriminator_autograd[i])
-        for param in self.attribute_discriminators.parameters():
-            param.requires_grad = bool(train_mode)
+        self._switch(self._discriminators(), train_mode)
 
     def generator_mode(self, train_mode=True):
-        for i, param in enumerate(self.generator.parameters()):
-            param.requires_grad = bool(train_mode and self.generator_param_autograd[i])
+        self._switch((self.generator,), train_mode)
 
     # ------------------------------------------------------------------------------------------------------------
     # initial VAE pre-training (cgn.py:621-674): one optimizer over every learnable parameter, no detach, no D

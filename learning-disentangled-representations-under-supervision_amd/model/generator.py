@@ -66,43 +66,36 @@ def _dropout_mask(x, drop_prob, training, legacy_noop):
 
 
 class Generator(nn.Module):
+    """Attributes `rnn` (LSTM over [word embedding | z | c]) and `fc` (hidden -> vocabulary), as in the reference;
+    the width of c is config.c_size (the reference hard-codes 1, generator.py:17,54)."""
 
     legacy_dropout_noop = True
 
     def __init__(self, params):
-        super(Generator, self).__init__()
-
+        super().__init__()
         self.params = params
-        c_size = getattr(params, "c_size", 1)
+        code = params.latent_variable_size + getattr(params, "c_size", 1)
+        H = params.decoder_rnn_size
+        self.rnn = hnn.LSTM(input_size=code + params.word_embed_size, hidden_size=H,
+                            num_layers=params.decoder_num_layers, batch_first=True)
+        self.fc = hnn.Linear(H, params.word_vocab_size)
 
-        self.rnn = hnn.LSTM(input_size=(self.params.latent_variable_size + c_size) + self.params.word_embed_size,
-                            hidden_size=self.params.decoder_rnn_size,
-                            num_layers=self.params.decoder_num_layers,
-                            batch_first=True)
-
-        self.fc = hnn.Linear(self.params.decoder_rnn_size, self.params.word_vocab_size)
+    def _run_rnn(self, words, code_rows, drop_prob, state):
+        """LSTM over words [rows, steps, E] with one code row [rows, Z+C] repeated at every step."""
+        mask = _dropout_mask(words, drop_prob, self.training, self.legacy_dropout_noop)
+        return self.rnn(_GenInputFn.apply(words, code_rows, mask), state)
 
     def only_decoder_beam(self, generator_input, zc, drop_prob, initial_state=None):
-        """Single call of the LSTM stack with carried state, generator.py:24-43 (used by the sampler)."""
-        [beam_batch_size, steps, _] = generator_input.size()
-        mask = _dropout_mask(generator_input, drop_prob, self.training, self.legacy_dropout_noop)
-        # generator.py:30-32: every seed's zc is repeated for its beams (Python-2 integer division in the reference)
-        reps = beam_batch_size // zc.size(0)
-        zc = zc.unsqueeze(0).expand(reps, zc.size(0), zc.size(1)).reshape(beam_batch_size, -1)
-        x = _GenInputFn.apply(generator_input, zc, mask)
-        rnn_out, final_state = self.rnn(x, initial_state)
-        return rnn_out, final_state
+        """generator.py:24-43 (sampler): the LSTM stack alone, state carried between calls. The zc block is repeated
+        whole until it covers the beam batch (row i gets seed i mod S, integer division as under Python 2)."""
+        rows = generator_input.size(0)
+        S = zc.size(0)
+        code_rows = zc.repeat(rows // S, 1)
+        return self._run_rnn(generator_input, code_rows, drop_prob, initial_state)
 
     def forward(self, generator_input, zc, drop_prob, initial_state=None):
-        [batch_size, seq_len, _] = generator_input.size()
-
-        mask = _dropout_mask(generator_input, drop_prob, self.training, self.legacy_dropout_noop)
-        x = _GenInputFn.apply(generator_input, zc, mask)
-
-        rnn_out, final_state = self.rnn(x, initial_state)
-        rnn_out = rnn_out.contiguous().view(-1, self.params.decoder_rnn_size)
-
-        result = self.fc(rnn_out)
-        result = result.view(batch_size, seq_len, self.params.word_vocab_size)
-
-        return result, final_state
+        """generator.py:45-64: logits [B, T, V] and the LSTM's final (h_n, c_n)."""
+        B, T = generator_input.shape[:2]
+        hidden, final_state = self._run_rnn(generator_input, zc, drop_prob, initial_state)
+        logits = self.fc(hidden.reshape(B * T, -1))
+        return logits.view(B, T, -1), final_state

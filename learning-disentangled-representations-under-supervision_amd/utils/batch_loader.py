@@ -8,8 +8,6 @@ train_lines = 900000 (batch_loader.py:87-104, :244) — CPU file handling outsid
 sentences instead. One deliberate difference: the character vocabulary is sorted (the reference takes set-iteration
 order, batch_loader.py:146-154, which changes from run to run under Python 3 hash randomisation).
 """
-import collections
-
 import numpy as np
 
 
@@ -54,10 +52,9 @@ class BatchLoader:
 
     # batch_loader.py:163-177
     def build_word_vocab(self, words):
-        word_counts = collections.Counter(words)
-        idx_to_word = [x[0] for x in word_counts.most_common()]
-        idx_to_word = list(sorted(idx_to_word)) + [self.pad_token, self.go_token, self.end_token]
-        return len(idx_to_word), idx_to_word, {x: i for i, x in enumerate(idx_to_word)}
+        """Distinct words in sorted order, then the three special tokens as the LAST indices (pad, go, end)."""
+        vocab = sorted(set(words)) + [self.pad_token, self.go_token, self.end_token]
+        return len(vocab), vocab, dict(zip(vocab, range(len(vocab))))
 
     # batch_loader.py:264-269 (kept as lists: the reference's ragged np.array is rejected by numpy 2.x)
     def create_tensors(self, data_words):
@@ -90,17 +87,19 @@ class BatchLoader:
 
     # batch_loader.py:341-345
     def go_input(self, batch_size):
-        go_word_input = [[self.word_to_idx[self.go_token]] for _ in range(batch_size)]
-        go_character_input = [[self.encode_characters(self.go_token)] for _ in range(batch_size)]
-        return np.array(go_word_input), np.array(go_character_input)
+        """One <go> step per sentence: word ids [batch, 1] and their character rows [batch, 1, max_word_len]."""
+        word = np.full((batch_size, 1), self.word_to_idx[self.go_token], dtype=np.int64)
+        chars = np.tile(np.asarray(self.encode_characters(self.go_token), dtype=np.int64), (batch_size, 1, 1))
+        return word, chars
 
     # batch_loader.py:352-370
     def decode_word(self, word_idx):
         return self.idx_to_word[int(word_idx)]
 
     def encode_characters(self, characters):
-        to_add = self.max_word_len - len(characters)
-        return [self.char_to_idx[i] for i in characters] + to_add * [self.char_to_idx['']]
+        """Character ids of one word, right-padded with the blind symbol to max_word_len."""
+        ids = [self.char_to_idx[ch] for ch in characters]
+        return ids + [self.char_to_idx[self.blind_symbol]] * (self.max_word_len - len(ids))
 
     def decode_characters(self, characters_idx):
         return ''.join(self.idx_to_char[i] for i in characters_idx)

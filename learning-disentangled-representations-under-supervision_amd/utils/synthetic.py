@@ -12,8 +12,9 @@ def word_embeddings(config, seed=1234):
 
 
 class _GenBatchLoader:
-    def __init__(self, config, L, train_lines, seed):
+    def __init__(self, config, L, train_lines, seed, val_lines=0):
         self.config, self.L, self.train_lines, self.seed = config, L, train_lines, seed
+        self.val_lines = val_lines
         # special tokens are the last three vocabulary indices (batch_loader.py:81-85, :170)
         V = config.word_vocab_size
         self.pad_token, self.go_token, self.end_token = '_', '>', '|'
@@ -42,11 +43,11 @@ class _GenBatchLoader:
 class SyntheticDataHandler:
     """Duck-types the parts of utils/data_handler.py DataHandler that the step closures touch."""
 
-    def __init__(self, config, batch_size, seq_len, num_batches=8, seed=1234):
+    def __init__(self, config, batch_size, seq_len, num_batches=8, seed=1234, val_lines=0, num_dev_batches=None):
         self.config, self.batch_size, self.L, self.seed = config, batch_size, seq_len, seed
         self.num_train_sentiment_batches = num_batches
-        self.num_dev_sentiment_batches = num_batches
-        self.gen_batch_loader = _GenBatchLoader(config, seq_len, batch_size * num_batches, seed)
+        self.num_dev_sentiment_batches = num_batches if num_dev_batches is None else num_dev_batches
+        self.gen_batch_loader = _GenBatchLoader(config, seq_len, batch_size * num_batches, seed, val_lines)
 
     def _labelled(self, batch_index, salt):
         rng = np.random.RandomState((self.seed + 104729 * batch_index + salt) % (2 ** 31))

@@ -83,6 +83,80 @@ def temp_coef(i):
 
 
 # --------------------------------------------------------------------------------------------------------------
+# Test aid (no counterpart in the reference): which side of each non-differentiable point the forward pass takes.
+# The step is piecewise smooth: ReLU gates (highway.py:39, discriminator_sentiment.py:64) and max-over-time winners
+# (tdnn.py:43, discriminator_sentiment.py:66). Where two candidates are tied to within fp32 rounding, an fp32
+# implementation may legitimately pick the other one, and the GRADIENT (not the loss) then differs by that gate's
+# whole contribution. While SELECT is a Selections object the modules below report every such choice to it; given the
+# choices an fp32 run made (`forced`), the oracle adopts them where - and only where - its own candidates are tied to
+# within `tie` (relative), and counts the adoptions. With SELECT = None (default) the plain torch ops run.
+# --------------------------------------------------------------------------------------------------------------
+class Selections:
+    def __init__(self, forced=None, tie=1e-5):
+        self.forced = forced or {}
+        self.tie = tie
+        self.scope = ""
+        self.adopted = {}   # site -> number of near-tied choices taken over from `forced`
+        self.refused = {}   # site -> number of differing choices that were NOT near ties (kept the oracle's own)
+        self.seen = []
+
+    def _count(self, site, take, differ):
+        n_take, n_ref = int(take.sum()), int((differ & ~take).sum())
+        if n_take:
+            self.adopted[site] = self.adopted.get(site, 0) + n_take
+        if n_ref:
+            self.refused[site] = self.refused.get(site, 0) + n_ref
+
+    def relu(self, name, pre):
+        site = self.scope + "/" + name
+        self.seen.append(site)
+        own = pre.detach() > 0
+        f = self.forced.get(site)
+        if f is not None:
+            f = f.to(own.device).bool()
+            differ = own != f
+            take = differ & (pre.detach().abs() < self.tie * pre.detach().abs().mean())
+            self._count(site, take, differ)
+            own = torch.where(take, f, own)
+        return pre * own.to(pre.dtype)
+
+    def maxpool(self, name, v, relu):
+        """v [N, C, P] -> [N, C]: max over P (then ReLU if `relu`); forced: [N, C] winner positions, -1 = gate closed."""
+        site = self.scope + "/" + name
+        self.seen.append(site)
+        d = v.detach()
+        thr = self.tie * d.abs().mean()
+        idx = d.argmax(2)
+        f = self.forced.get(site)
+        if f is not None:
+            f = f.to(idx.device).long()
+            fpos = f.clamp(min=0)
+            differ = (f >= 0) & (fpos != idx)
+            gap = d.gather(2, idx.unsqueeze(2)).squeeze(2) - d.gather(2, fpos.unsqueeze(2)).squeeze(2)
+            take = differ & (gap < thr)
+            self._count(site + ":winner", take, differ)
+            idx = torch.where(take, fpos, idx)
+        val = v.gather(2, idx.unsqueeze(2)).squeeze(2)
+        if not relu:
+            return val
+        is_open = val.detach() > 0
+        if f is not None:
+            differ = is_open != (f >= 0)
+            take = differ & (val.detach().abs() < thr)
+            self._count(site + ":gate", take, differ)
+            is_open = torch.where(take, f >= 0, is_open)
+        return val * is_open.to(val.dtype)
+
+
+SELECT = None
+
+
+def _scope(name):
+    if SELECT is not None:
+        SELECT.scope = name
+
+
+# --------------------------------------------------------------------------------------------------------------
 # selfModules/tdnn.py:8-52
 # --------------------------------------------------------------------------------------------------------------
 class TDNN(nn.Module):
@@ -98,7 +172,10 @@ class TDNN(nn.Module):
         B, L, W, Cc = x.shape  # tdnn.py:34
         x = x.reshape(-1, self.params.max_word_len, self.params.char_embed_size).transpose(1, 2).contiguous()  # :40
         xs = [torch.tanh(F.conv1d(x, k)) for k in self.kernels]  # :42 (no bias, stride 1, no pad)
-        xs = [v.max(2)[0] for v in xs]  # :43 (keepdim-era squeeze(2) dropped)
+        if SELECT is not None:
+            xs = [SELECT.maxpool("tdnn%d" % i, v, relu=False) for i, v in enumerate(xs)]
+        else:
+            xs = [v.max(2)[0] for v in xs]  # :43 (keepdim-era squeeze(2) dropped)
         return torch.cat(xs, 1).view(B, L, -1)  # :45-46
 
 
@@ -153,7 +230,10 @@ class Highway(nn.Module):
     def forward(self, x):  # highway.py:27-46
         for l in range(self.num_layers):
             gate = torch.sigmoid(self._gate[l](x))
-            nonlinear = self.f(self._nonlinear[l](x))
+            if SELECT is not None and self.f is F.relu:
+                nonlinear = SELECT.relu("hw%d" % l, self._nonlinear[l](x))
+            else:
+                nonlinear = self.f(self._nonlinear[l](x))
             linear = self._linear[l](x)
             x = gate * nonlinear + (1 - gate) * linear
         return x
@@ -219,6 +299,9 @@ class Sentiment_CNN(nn.Module):
 
     def features(self, x):
         x = x.unsqueeze(1)  # :62
+        if SELECT is not None:  # max_t relu(v) = relu(max_t v)
+            xs = [SELECT.maxpool("conv%d" % i, conv(x).squeeze(3), relu=True) for i, conv in enumerate(self.convs1)]
+            return torch.cat(xs, 1)
         xs = [F.relu(conv(x)).squeeze(3) for conv in self.convs1]  # :64
         xs = [F.max_pool1d(i, i.size(2)).squeeze(2) for i in xs]  # :66
         return torch.cat(xs, 1)  # :68
@@ -317,6 +400,7 @@ def prep_enc_gen_training(model):
 # --------------------------------------------------------------------------------------------------------------
 def discriminator_forward(model, encoder_word_input, uniform):
     """cgn.py:151-172; t.bernoulli(softmax[:,1]) (:170) becomes (uniform < p1) with `uniform` ~ U[0,1)[B] given."""
+    _scope("infer")
     with torch.no_grad():
         x = model.embedding.get_word_embed(encoder_word_input)  # :163
         logit = model.sentiment_discriminator(x)  # eval mode => no dropout (:151)
@@ -343,8 +427,10 @@ def disc_train_step(model, optimizer, x_labelled, y_labelled, x_generated, c_gen
     for a, D in enumerate(model.discriminators()):  # the reference: one discriminator (a = 0)
         y_l = y_labelled if C == 1 else y_labelled[:, a]
         c_g = c_generated.view(-1) if C == 1 else c_generated[:, a]
+        _scope("disc_l%d" % a)
         logit = D(model.embedding.word_embed(x_labelled), mask_labelled)  # :303-304
         ce_l = F.cross_entropy(logit, y_l.long())  # :306
+        _scope("disc_g%d" % a)
         logit_generated = D(model.embedding.word_embed(x_generated), mask_generated)  # :315-316
         log_softmax_generated = F.log_softmax(logit_generated, dim=1)  # :318
         softmax_generated = torch.exp(log_softmax_generated)  # :319
@@ -382,6 +468,7 @@ def enc_gen_train_step(model, encoder_optimizer, generator_optimizer, batch, c_t
     generator_optimizer.zero_grad()  # :1052
     encoder_word_input, encoder_character_input, gen_word_input, _, target = batch
     batch_size = encoder_word_input.size(0)
+    _scope("enc")
     encoder_input = model.embedding(encoder_word_input, encoder_character_input)  # :1063
     z_out, std_out, logvar_out, mu_out = model.encode_for_z(encoder_input, eps)  # :1065
     z = z_out.detach().clone().requires_grad_(True)  # :1067 Variable(z_out.data, requires_grad=True)
@@ -403,12 +490,15 @@ def enc_gen_train_step(model, encoder_optimizer, generator_optimizer, batch, c_t
     softmax_output = torch.exp(log_softmax)  # :1103
     out_embedding = torch.mm(softmax_output, model.embedding.word_embed.weight)  # :1106
     out_embedding = out_embedding.view(batch_size, -1, out_embedding.size(1))[:, :-1, :]  # :1108
+    _scope("soft0")
     c_reconstructed = model.sentiment_discriminator(out_embedding)  # :1114 (eval mode: no dropout)
     c_loss = F.cross_entropy(c_reconstructed, c.long()[:, 0])  # :1117-1118
     for a, D in enumerate(model.attribute_discriminators, 1):  # multi-attribute extension: one c-loss per attribute
+        _scope("soft%d" % a)
         c_loss = c_loss + F.cross_entropy(D(out_embedding), c.long()[:, a])
     total_reconstruction_loss = cfg.lambda_c * c_loss  # :1120
     if calc_z_loss:  # :1122-1137
+        _scope("recon")
         encoder_character_embedding = model.embedding.get_character_embed(encoder_character_input)
         encoder_reconstructed_input = torch.cat([out_embedding, encoder_character_embedding], dim=2)
         z_recon, std_recon, _, mu_recon = model.encode_for_z(encoder_reconstructed_input, eps_recon)

@@ -37,7 +37,6 @@ def _build(dev, eos_bias=0.0, seed=5, scale=3.0):
 @pytest.mark.parametrize("S,K,eos_bias", [(6, 5, 0.0), (10, 10, 2.5), (3, 1, 0.0), (7, 4, 4.0)])
 def test_beam_sampler_matches_oracle(dev, S, K, eos_bias, graphed, monkeypatch):
     from ldrs_amd.hip import sampler as hs
-    monkeypatch.setattr(hs.BeamSampler, "_cache", {})
     orig_init = hs.BeamSampler.__init__
     monkeypatch.setattr(hs.BeamSampler, "__init__", lambda self, eng, use_graph=True: orig_init(self, eng, graphed))
     cfg, ocfg, oracle, model, handler = _build(dev, eos_bias)

@@ -57,61 +57,6 @@ def rel(a, ref):
     return (a - ref).norm().item() / max(ref.norm().item(), 1e-300)
 
 
-def kink_margin(oracle, data, calc_z, gen_drop=None, gstep=5000):
-    """Smallest distance of the fp64 oracle's forward pass from a non-differentiable point: a ReLU input at 0
-    (highway nonlinear branch, text-CNN) or a max-over-time tie (text-CNN, TDNN). Where this is within fp32 rounding
-    (~1e-5 here) the fp32 path may legitimately take the other side of ONE gate and that tensor's gradient differs by
-    that gate's contribution; the test then widens the gradient tolerance (never the loss tolerance)."""
-    margins = []
-    hooks = []
-
-    def relu_in(_m, _i, out):
-        margins.append(out.detach().abs().min().item())
-
-    def pool_in(_m, _i, out):  # conv output [B, Co, P, 1] (text-CNN)
-        o = out.detach().squeeze(3)
-        if o.shape[2] > 1:
-            top = o.topk(2, dim=2)[0]
-            live = top[..., 0] > 0
-            if live.any():
-                margins.append((top[..., 0] - top[..., 1])[live].min().item())
-        margins.append(o.max(2)[0].abs().min().item())
-
-    for lin in oracle.encoder.hw1._nonlinear:
-        hooks.append(lin.register_forward_hook(relu_in))
-    for disc in oracle.discriminators():
-        for conv in disc.convs1:
-            hooks.append(conv.register_forward_hook(pool_in))
-    import torch.nn.functional as F
-    with torch.no_grad():
-        x = oracle.embedding.char_embed(data["enc_char"].reshape(-1, oracle.config.max_word_len)).transpose(1, 2)
-        for k in oracle.embedding.TDNN.kernels:
-            o = F.conv1d(x, k)
-            if o.shape[2] > 1:
-                top = o.topk(2, dim=2)[0]
-                margins.append((top[..., 0] - top[..., 1]).min().item())
-        emb = oracle.embedding.word_embed
-        def D(x):
-            for disc in oracle.discriminators():
-                disc(x)
-        D(emb(data["x_labelled"])), D(emb(data["x_generated"])), D(emb(data["enc_word"]))
-        enc_in = oracle.embedding(data["enc_word"], data["enc_char"])
-        z, std, lv, mu = oracle.encode_for_z(enc_in, data["eps"])
-        # the soft-embedding passes (c- and z-reconstruction) see the pre-step weights too
-        c, _ = O.discriminator_forward(oracle, data["enc_word"], data["c_uniform"])
-        logits, _ = oracle.generator(emb(data["dec_word"]), torch.cat([z, c.view(z.shape[0], -1)], 1), gen_drop)
-        B = z.shape[0]
-        ls = torch.log_softmax(logits.view(-1, logits.shape[-1]) / O.temp_coef(gstep), 1)
-        soft = (ls.exp() @ emb.weight).view(B, -1, emb.weight.shape[1])[:, :-1]
-        D(soft)
-        if calc_z:
-            oracle.encode_for_z(torch.cat([soft, oracle.embedding.get_character_embed(data["enc_char"])], 2),
-                                data["eps_recon"])
-    for h in hooks:
-        h.remove()
-    return min(margins)
-
-
 class Handler:
     """Feeds the closures the oracle's synthetic batch through the reference's data_handler interface."""
 
@@ -125,6 +70,32 @@ class Handler:
 
     def create_sentiment_batch(self, s):
         return torch.tensor(s, dtype=torch.int64)
+
+
+HANDLER = Handler(None, None)
+
+
+def forced_selections(sel, ocfg):
+    """The HIP pass's gate / winner choices (hip/step.py `_cap_sel`) keyed by the oracle's site names."""
+    out = {}
+    for key, t in sel.items():
+        t = t.cpu()
+        scope, kind = key.split("/")
+        if kind.startswith("hw"):
+            out[key] = t
+        elif kind == "tdnn":  # [N, S] winner positions, one column block per kernel width
+            col = 0
+            for i, (_, od) in enumerate(ocfg.kernels):
+                out["%s/tdnn%d" % (scope, i)] = t[:, col:col + od]
+                out["recon/tdnn%d" % i] = t[:, col:col + od]  # the z-reconstruction pass re-embeds the same characters
+                col += od
+        else:  # text-CNN: [B, F] winner positions (-1 = ReLU gate closed), one block per filter width
+            Co = ocfg.sentiment_kernel_num
+            for i in range(len(ocfg.sentiment_kernel_size)):
+                out["%s/conv%d" % (scope, i)] = t[:, i * Co:(i + 1) * Co]
+    if not any(k.startswith("recon/hw") for k in sel):  # no z-reconstruction pass in this step
+        out = {k: v for k, v in out.items() if not k.startswith("recon/")}
+    return out
 
 
 def build(name, dev, seed=0):
@@ -162,20 +133,54 @@ def test_wake_sleep_step_bf16_mode(dev, name, B, calc_z):
         ops.set_compute(prev)
 
 
-def _gtol(gtol, pname, bf16):
-    """One bar for every tensor, in both modes. (The bf16 mode keeps the products that feed ReLU / max-over-time
-    selections in fp32 - hip/engine.py - so no tensor needs a wider one.)"""
-    return gtol
+class Report:
+    """Every comparison of one parity case: (kind, tensor, step, measured relative error, bar). Nothing is asserted
+    until the case is over, so a failing case still lists every error; with CGN_PARITY_REPORT=<dir> the table is also
+    written to <dir>/parity_<case>.txt (tools/parity_report.py commits those under profiles/)."""
+
+    def __init__(self, case):
+        self.case, self.rows, self.notes = case, [], []
+
+    def add(self, kind, name, step, err, bar):
+        self.rows.append((kind, name, step, float(err), float(bar)))
+
+    def note(self, text):
+        self.notes.append(text)
+
+    def text(self):
+        out = ["# parity case %s: relative Frobenius error of the HIP step vs the fp64 oracle" % self.case]
+        out += ["# " + n for n in self.notes]
+        out.append("%-8s %-62s %4s %10s %8s %s" % ("kind", "tensor", "step", "error", "bar", ""))
+        for kind, name, step, err, bar in self.rows:
+            out.append("%-8s %-62s %4d %10.2e %8.0e %s" % (kind, name, step, err, bar, "" if err < bar else "FAIL"))
+        worst = {}
+        for kind, name, step, err, bar in self.rows:
+            worst[kind] = max(worst.get(kind, 0.0), err)
+        out.append("# worst per kind: " + ", ".join("%s %.2e" % kv for kv in sorted(worst.items())))
+        return "\n".join(out) + "\n"
+
+    def finish(self):
+        import os
+        d = os.environ.get("CGN_PARITY_REPORT")
+        if d:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "parity_%s.txt" % self.case), "w") as f:
+                f.write(self.text())
+        bad = [r for r in self.rows if not r[3] < r[4]]
+        assert not bad, "parity failures:\n" + "\n".join("%s %s step %d: %.3e >= %.0e" % r for r in bad)
 
 
 def _step_parity(dev, name, B, calc_z, TOL):
     bf16 = TOL > 1e-3
+    rep = Report("%s_B%d_%s%s" % (name, B, "z" if calc_z else "noz", "_bf16" if bf16 else ""))
     ocfg, oracle, cfg, model = build(name, dev)
     L = ocfg.max_seq_len - 1
     F_ = len(ocfg.sentiment_kernel_size) * ocfg.sentiment_kernel_num
     opts = O.make_optimizers(oracle)
-    handler = None
-    disc_train = enc_gen_train = None
+    HANDLER.cfg = cfg
+    disc_train = model.discriminator_sentiment_trainer(HANDLER, True)
+    enc_gen_train = model.train_encoder_generator()
+    GTOL = TOL
     # three steps: Adam moments and the changed weights are exercised too. bf16 mode: ONE step, the comparison the bar is
     # stated for (identical weights); after a step the two paths' weights differ by Adam's sign-like first updates
     # (+-lr wherever a tiny gradient element changes sign), and later gradients are no longer taken at the same point
@@ -187,24 +192,8 @@ def _step_parity(dev, name, B, calc_z, TOL):
                      gen_drop=(torch.rand(B, L + 1, ocfg.word_embed_size, generator=g) < 0.7).double() / 0.7)
         ddata = {k: (v.double() if v.is_floating_point() else v) for k, v in data.items()}
         gstep = 5000 + 1000 * step
-        cap_o = {}
-        margin = kink_margin(oracle, ddata, calc_z, masks["gen_drop"], gstep)
-        GTOL = TOL if (margin > 2e-5 or bf16) else 1e-2  # see kink_margin
-        before = {n: p.detach().clone() for n, p in oracle.named_parameters()}
-        d_o, c_o, eg_o = O.wake_sleep_step(oracle, opts, ddata, gstep, calc_z_loss=calc_z, masks=masks, capture=cap_o)
-
-        # ---- HIP path through the reference-API closures ---------------------------------------------------------
-        handler = Handler(data, cfg)
-        if disc_train is None:
-            disc_train = model.discriminator_sentiment_trainer(handler, True)
-            enc_gen_train = model.train_encoder_generator()
-        else:
-            disc_train.__closure__  # same closures, new data through the handler object below
-        # closures captured the first handler; point it at this step's data
-        if step > 0:
-            first_handler.d = data
-        else:
-            first_handler = handler
+        # ---- HIP path first, through the reference-API closures ---------------------------------------------------
+        HANDLER.d = data
         cap = {}
         model.prep_disc_training()
         d_h = disc_train(data["x_generated"].tolist(), data["c_generated"].float().view(B, -1), 0,
@@ -214,13 +203,26 @@ def _step_parity(dev, name, B, calc_z, TOL):
                  data["target"].numpy()]
         model.discriminator_mode(train_mode=False)
         c_h = model.discriminator_forward(batch, B, True, uniform=data["c_uniform"])
-        assert torch.equal(c_h.cpu().double(), c_o), "inferred c differs"
         model.prep_enc_gen_training()
         eg_h = enc_gen_train(batch, B, True, masks["gen_drop"].float().to(dev), c_h, gstep, calc_z_loss=calc_z,
                              eps=data["eps"], capture=cap)
 
+        # ---- fp64 oracle, on the smooth region the fp32 pass took wherever its own candidates are tied ------------
+        cap_o = {}
+        before = {n: p.detach().clone() for n, p in oracle.named_parameters()}
+        O.SELECT = sel = O.Selections(forced_selections(cap["sel"], ocfg), tie=1e-5)
+        try:
+            d_o, c_o, eg_o = O.wake_sleep_step(oracle, opts, ddata, gstep, calc_z_loss=calc_z, masks=masks, capture=cap_o)
+        finally:
+            O.SELECT = None
+        assert torch.equal(c_h.cpu().double(), c_o), "inferred c differs"
+        missing = set(sel.forced) - set(s_.split(":")[0] for s_ in sel.seen)
+        assert not missing, ("selection sites the oracle never visited", missing)
+        rep.note("step %d: near-tied selections taken over from the fp32 pass: %s; differing but NOT tied (kept): %s"
+                 % (step, dict(sel.adopted) or "none", dict(sel.refused) or "none"))
+
         for a, b, nm in zip(d_h, d_o, ("total", "ce_l", "gen_loss", "ce_g", "entropy")):
-            assert rel(a, b) < TOL, ("disc loss", nm, step)
+            rep.add("loss", "disc." + nm, step, rel(a, b), TOL)
         names = ("ce", "kld", "z_loss", "c_loss", "kld_coef", "temp", "enc_loss", "gen_loss")
         for a, b, nm in zip(eg_h, eg_o, names):
             a = a if isinstance(a, torch.Tensor) else torch.tensor(float(a))
@@ -230,15 +232,13 @@ def _step_parity(dev, name, B, calc_z, TOL):
                 continue
             # bf16 mode: z_loss is a squared DIFFERENCE of two nearly equal codes (cgn.py:47-57), so the ~3e-3 error of the
             # re-encoded code shows up amplified in it (measured 1.3e-2 on "odd", 4e-3 on "mid"); its bar is 3e-2
-            assert rel(a, b) < (3e-2 if (bf16 and nm == "z_loss") else TOL), ("enc-gen loss", nm, step, float(a), float(b))
-        assert rel(cap["g"], cap_o["g"]) < GTOL, ("g", step, margin)
+            rep.add("loss", "encgen." + nm, step, rel(a, b), 3e-2 if (bf16 and nm == "z_loss") else TOL)
+        rep.add("grad", "g = d(79 CE + recon)/dz", step, rel(cap["g"], cap_o["g"]), GTOL)
         for key, okey, prefix in (("disc_grads", "disc_grads", "sentiment_discriminator."),
                                   ("gen_grads", "gen_grads", "generator."), ("enc_grads", "enc_grads", "")):
             for n, gref in cap_o[okey].items():
                 full = n if (n.startswith(prefix) or n.startswith("attribute_discriminators.")) else prefix + n
-                if bf16:  # diagnostics: python -m pytest -s prints the per-tensor errors of the bf16 mode
-                    print("bf16 %-5s step %d %-55s %.2e" % (name, step, full, rel(cap[key][full], gref)))
-                assert rel(cap[key][full], gref) < _gtol(GTOL, full, bf16), (key, full, step, rel(cap[key][full], gref), margin)
+                rep.add("grad", full, step, rel(cap[key][full], gref), GTOL)
         after_o = dict(oracle.named_parameters())
         after_h = dict(model.named_parameters())
         for n, p0 in before.items():
@@ -247,8 +247,11 @@ def _step_parity(dev, name, B, calc_z, TOL):
             if upd_o.abs().max() == 0:
                 assert upd_h.abs().max() < 1e-7, n  # frozen (word embedding)
             else:
-                assert rel(upd_h, upd_o) < (max(2e-3, 10 * GTOL) if not bf16 else 0.5), ("update", n, step, rel(upd_h, upd_o))
-                assert rel(after_h[n], after_o[n]) < (1e-3 if bf16 else 1e-6 if GTOL == TOL else 1e-4), ("weights", n, step)
+                # Adam's first updates are sign-like (+-lr wherever |g| >> eps), so the UPDATE amplifies the gradient
+                # error of elements near zero; the weights themselves are held to 1e-6
+                rep.add("update", n, step, rel(upd_h, upd_o), 0.5 if bf16 else max(2e-3, 10 * GTOL))
+                rep.add("weight", n, step, rel(after_h[n], after_o[n]), 1e-3 if bf16 else 1e-6)
+    rep.finish()
 
 
 def test_validation_closure_is_forward_only(dev):
