@@ -181,6 +181,48 @@ int cgn_lstm_seq_bwd_f32(void* stream, const cgn_lstm_bwd_seq* seqs /* host */, 
 int cgn_lstm_seq_bwd_persistent_f32(void* stream, const cgn_lstm_bwd_seq* seqs /* host */, int32_t nseq, int32_t B,
                                     int32_t T, int32_t H, void* sync_ws, int64_t sync_ws_bytes);
 
+/* Two stacked LSTM layers in ONE persistent launch each way (the generator's nn.LSTM(num_layers=2, batch_first),
+ * model/generator.py:17-20,58, zero initial state as model/cgn.py:1082 calls it). The layers form a wavefront, layer 1
+ * one timestep behind layer 0; layer 1's input projection h0·W_ih1ᵀ + b_ih1 + b_hh1 is folded into its recurrence
+ * (K = 2H over [h0_t ; h1_{t-1}]), and in the backward pass the gradient wrt h0 (dg1·W_ih1) into the bottom layer's
+ * (K = 8H over [dg1_t ; dg0_{t+1}]). Same buffers and layouts as cgn_lstm_seq_fwd/bwd_f32; layer 1 has no xg.
+ * Gradients wrt the final states are zero, gradients wrt the initial states are not produced.
+ * cgn_lstm2_persistent_query: *sync_bytes = scratch size (as cgn_lstm_persistent_query), 0 = shape not eligible
+ * (H % 16, H <= 512, 2 * ceil(B/16) * H/16 workgroups <= CUs): run the layers one after the other then. */
+typedef struct cgn_lstm2_fwd {
+    const float* xg0;       /* [B,T,4H] layer-0 input projections incl. both biases */
+    const float* xg0_extra; /* nullable [B,4H], added at every timestep */
+    const float* w_hh0;     /* [4H,H] */
+    const float* w_ih1;     /* [4H,H] */
+    const float* w_hh1;     /* [4H,H] */
+    const float* b_ih1;     /* [4H] */
+    const float* b_hh1;     /* [4H] */
+    float* hbuf0;
+    float* cbuf0;
+    float* gates0;
+    float* hbuf1;
+    float* cbuf1;
+    float* gates1;
+} cgn_lstm2_fwd;
+typedef struct cgn_lstm2_bwd {
+    const float* w_hh0; /* untransposed [4H,H] weights */
+    const float* w_ih1;
+    const float* w_hh1;
+    const float* cbuf0;
+    const float* gates0;
+    const float* cbuf1;
+    const float* gates1;
+    const float* dh_ext1; /* nullable: gradient wrt the emitted h1, element (b,t,j) at dh_ext1[b*dh_bs + t*dh_ts + j] */
+    float* dgates0;       /* [B,T,4H] out */
+    float* dgates1;       /* [B,T,4H] out */
+    int64_t dh_bs, dh_ts;
+} cgn_lstm2_bwd;
+int cgn_lstm2_persistent_query(int32_t B, int32_t T, int32_t H, int64_t* sync_bytes);
+int cgn_lstm2_fwd_persistent_f32(void* stream, const cgn_lstm2_fwd* d /* host */, int32_t B, int32_t T, int32_t H,
+                                 void* sync_ws, int64_t sync_ws_bytes);
+int cgn_lstm2_bwd_persistent_f32(void* stream, const cgn_lstm2_bwd* d /* host */, int32_t B, int32_t T, int32_t H,
+                                 void* sync_ws, int64_t sync_ws_bytes);
+
 /* ------------------------------------------------------------------------------------------------------------
  * One beam-search step for S sentences x K beams (rows r = s*K + k), replacing Beam.advance
  * (utils/beam_search.py:68-99) and the per-sentence state reordering of model/cgn.py:813-838 in the sleep-phase

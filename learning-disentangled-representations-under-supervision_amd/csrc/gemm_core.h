@@ -14,6 +14,8 @@
 //     (bitwise reproducible, no float atomics);
 //   * blockIdx -> tile mapping is XCD-aware: blocks that share an XCD (blockIdx % 8) walk neighbouring tiles.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace cgn_gemm {
@@ -236,7 +238,12 @@ struct TileLoader {
         }
     }
 
-    // Mask/transform the staged registers and write them into the LDS image dst[ROWS][LDK].
+    // Transform the staged registers and write them into the LDS image dst[ROWS][LDK]. MASK = true zeroes what lies
+    // beyond kend (the K tail MUST contribute zeros) and beyond the last row; MASK = false is for tiles that lie wholly
+    // inside [kbeg, kend): rows beyond the operand were loaded from a clamped (valid) address and only ever reach output
+    // rows / columns that the epilogue never stores, so they need no zeroing - and the ~40 compare/select instructions
+    // per K step that the masks cost leave the loop that feeds the MFMAs.
+    template <bool MASK = true>
     __device__ __forceinline__ void store(int st, float* __restrict__ dst, int k0, int kend, float scale) const {
         const int tid = threadIdx.x;
         if constexpr (KC) {
@@ -254,7 +261,8 @@ struct TileLoader {
                     // hardware exponential (v_exp_f32 on the base-2 argument): ~1e-6 relative, two instructions
                     // instead of expf's ~15 in the loop that feeds the MFMAs (x <= 0 here: x*scale - lse)
                     if constexpr (EXP) x = __expf(x * scale - rparam[i]);
-                    v[j] = (rok[i] && k + j < kend) ? x : 0.f;
+                    if constexpr (MASK) x = (rok[i] && k + j < kend) ? x : 0.f;
+                    v[j] = x;
                 }
                 if constexpr (BF)
                     *reinterpret_cast<u32x2*>(dst + (r + i * RS) * LDK + q * 2) = pack_bf16x4(v);
@@ -268,7 +276,8 @@ struct TileLoader {
             for (int i = 0; i < 4; ++i) {
                 float v[KP];
 #pragma unroll
-                for (int j = 0; j < KP; ++j) v[j] = (rok4[i] && k0 + kl + j < kend) ? regs[st][j][i] : 0.f;
+                for (int j = 0; j < KP; ++j)
+                    v[j] = (!MASK || (rok4[i] && k0 + kl + j < kend)) ? regs[st][j][i] : 0.f;
                 if constexpr (BF) {
 #pragma unroll
                     for (int j = 0; j < KP; j += 2)
@@ -290,7 +299,7 @@ struct TileLoader {
             for (int i = 0; i < PER; ++i) {
                 f32x4 v = regs[st][i];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (rok[0] && k0 + kl + 4 * i + j < kend) ? v[j] : 0.f;
+                for (int j = 0; j < 4; ++j) v[j] = (!MASK || (rok[0] && k0 + kl + 4 * i + j < kend)) ? v[j] : 0.f;
                 if constexpr (BF)
                     *reinterpret_cast<u32x2*>(dst + row * LDK + (kl + 4 * i) / 2) = pack_bf16x4(v);
                 else
@@ -360,104 +369,125 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
                 for (int c = 0; c < NC; ++c) acc[c][i][j][r] = 0.f;
 
     // Pipeline (one barrier per K step, LDS double-buffered, S tiles of global loads in flight):
-    //   tile j lives in register stage j % S from its load until it is written to LDS buffer j & 1
-    //   step kt:  write tile kt+1 (loaded during step kt-S) into buf[(kt+1)&1]
-    //             issue the global loads of tile kt+1+S into the stage just freed
-    //             MFMAs on buf[kt&1]
-    //             barrier
-    // The loop is unrolled by U = lcm(S, 2) so that stage and buffer indices are compile-time constants.
+    //   tile j lives in register stage j % S from its load until it is written to LDS buffer j & 1.
+    //   A K step is NBLK blocks of MFMAs (8 k each for fp32, 16 for bf16 operands); the fragments of a block are read
+    //   from LDS one block ahead (register double buffer fa/fb), ACROSS the step boundary too:
+    //   step kt:  block 0:         read fragments of block 1; write tile kt+1 (loaded during step kt-S) into
+    //                              buf[(kt+1)&1]; issue the global loads of tile kt+1+S; MFMAs of block 0
+    //             blocks 1..NBLK-2: read fragments of the next block; MFMAs
+    //             block NBLK-1:    barrier (tile kt+1 is complete, every read of tile kt has returned); read the
+    //                              fragments of block 0 of tile kt+1; MFMAs of block NBLK-1
+    //   so a wave never sits in front of an LDS round trip with an empty MFMA pipe: the reads issued behind the barrier
+    //   land under the last block's MFMAs. (Before this ordering a lone block per CU - every mid-size product of the
+    //   CGN step - ran at half its MFMA rate: barrier, LDS store, LDS read, THEN the first MFMA of the step.)
+    // Tiles that lie wholly inside [kbeg, kend) are written to LDS unmasked (hot loop); the last steps, whose next tile
+    // is partial or past the end, run the same body with the masked store. Both loops are unrolled by U = lcm(S, 2)
+    // multiples so that stage and buffer indices are compile-time constants.
     // Loads and LDS writes past the last tile are not skipped (that would need a branch, see TileLoader::load): they
     // re-read the block's first quads (L1/L2 hits) and write a buffer nobody reads again.
     const int nk = (kend - kbeg + BK - 1) / BK;
+    const int nfull = (kend - kbeg) / BK;  // tiles wholly inside the K range
     if (nk > 0) {
 #pragma unroll
         for (int j = 0; j < S; ++j) {
             la.load(j, p.A, p.ak, kbeg + j * BK, kbeg, kend);
             lb.load(j, p.B, p.bk, kbeg + j * BK, kbeg, kend);
         }
-        la.store(0, lds, kbeg, kend, a_scale);
-        lb.store(0, lds + TILE, kbeg, kend, 0.f);
+        la.template store<true>(0, lds, kbeg, kend, a_scale);
+        lb.template store<true>(0, lds + TILE, kbeg, kend, 0.f);
         la.load(0, p.A, p.ak, kbeg + S * BK, kbeg, kend);
         lb.load(0, p.B, p.bk, kbeg + S * BK, kbeg, kend);
     }
     __syncthreads();
 
     const int fr = lane & 31;  // fragment row/col
-    const int fk = lane >> 5;  // k-slice within the 32x32x2 step
-    // U steps per trip, a multiple of lcm(S, 2): hipcc's wait-count pass is exact inside the unrolled body but
-    // waits for ALL outstanding loads at the first LDS store after the loop header, so make trips long.
-    constexpr int U = g_unroll_mult * ((S % 2 == 0) ? S : 2 * S);
-    for (int kt0 = 0; kt0 < nk; kt0 += U) {
+    const int fk = lane >> 5;  // k-slice within the MFMA's k step
+    constexpr int KB = BF ? 16 : 8;   // k per block of MFMAs
+    constexpr int NBLK = BK / KB;     // blocks per K step
+    static_assert(NBLK >= 2 && NBLK % 2 == 0, "the fragment double buffer wraps at the step boundary");
+    // fragment registers: [double buffer][tile index]; fp32: 4 consecutive k of one row = one ds_read_b128, bf16: 8 k
+    typedef typename std::conditional<BF, bf16x8, f32x4>::type frag_t;
+    frag_t fa[2][TW], fb[2][TW];
+    // lane's fragment base inside an operand image (4-byte words)
+    const int a_lane = (wm * (BT / 2) + fr) * LDK + 4 * fk;
+    const int b_lane = (wn * (BT / 2) + fr) * LDK + 4 * fk;
+    auto read_frags = [&](const float* As_, const float* Bs_, int jb, int slot) {
+        // block jb: k = jb*KB .. jb*KB+KB-1; lane half fk holds 4 (fp32) / 8 (bf16) consecutive k = 4 words either way
+        constexpr int WPB = BF ? 8 : 8;  // words per block per row: fp32 8 floats; bf16 16 halves = 8 words
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int kt = kt0 + u;
-            if (kt >= nk) break;  // block-uniform
-            const float* As = lds + (u & 1) * 2 * TILE;
-            const float* Bs = As + TILE;
-            {
-                const int st = (u + 1) % S;
-                float* An = lds + ((u + 1) & 1) * 2 * TILE;
-                const int k1 = kbeg + (kt + 1) * BK;
-                la.store(st, An, k1, kend, a_scale);
-                lb.store(st, An + TILE, k1, kend, 0.f);
+        for (int i = 0; i < TW; ++i)
+            fa[slot][i] = *reinterpret_cast<const frag_t*>(As_ + a_lane + i * 32 * LDK + jb * WPB);
+#pragma unroll
+        for (int j = 0; j < TW; ++j)
+            fb[slot][j] = *reinterpret_cast<const frag_t*>(Bs_ + b_lane + j * 32 * LDK + jb * WPB);
+    };
+    auto mfma_block = [&](int slot) {
+        if constexpr (BF) {
+#pragma unroll
+            for (int i = 0; i < TW; ++i)
+#pragma unroll
+                for (int j = 0; j < TW; ++j)
+                    acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot][i], fb[slot][j], acc[0][i][j], 0, 0, 0);
+        } else {
+            // K order inside a block: lane half fk holds k = 4fk + e for the e-th MFMA (any permutation of k is legal as
+            // long as A and B use the same one)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TW; ++i)
+#pragma unroll
+                    for (int j = 0; j < TW; ++j)
+                        acc[e % NC][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][i][e], fb[slot][j][e],
+                                                                                 acc[e % NC][i][j], 0, 0, 0);
+        }
+    };
+    if (nk > 0) read_frags(lds, lds + TILE, 0, 0);
+
+    // one K step; u = step index within the unrolled trip (compile-time after unrolling), MASK = masked LDS store
+    auto k_step = [&](auto mask_tag, int u, int kt) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        const float* As = lds + (u & 1) * 2 * TILE;
+        const float* Bs = As + TILE;
+        float* An = lds + ((u + 1) & 1) * 2 * TILE;
+        const int st = (u + 1) % S;
+        const int k1 = kbeg + (kt + 1) * BK;
+#pragma unroll
+        for (int jb = 0; jb < NBLK; ++jb) {
+            if (jb + 1 < NBLK) {
+                read_frags(As, Bs, jb + 1, (jb + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);  // issued BEFORE this block's MFMAs, which then cover the round trip
+            }
+            if (jb == 0) {
+                la.template store<MASK>(st, An, k1, kend, a_scale);
+                lb.template store<MASK>(st, An + TILE, k1, kend, 0.f);
                 la.load(st, p.A, p.ak, k1 + S * BK, kbeg, kend);
                 lb.load(st, p.B, p.bk, k1 + S * BK, kbeg, kend);
             }
-            if constexpr (BF) {
-                // bf16 operands: a lane's fragment of one 32x32x16 step is 8 consecutive k of its row = ONE 16-byte LDS
-                // read (row stride 2*BK + 16 bytes: 16 consecutive rows fall on 16 different 16-byte slots).
-                const unsigned* ap = reinterpret_cast<const unsigned*>(As) + (wm * (BT / 2) + fr) * LDK + 4 * fk;
-                const unsigned* bp = reinterpret_cast<const unsigned*>(Bs) + (wn * (BT / 2) + fr) * LDK + 4 * fk;
-                bf16x8 a8[BK / 16][TW], b8[BK / 16][TW];
-#pragma unroll
-                for (int jb = 0; jb < BK / 16; ++jb) {
-#pragma unroll
-                    for (int i = 0; i < TW; ++i)
-                        a8[jb][i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * LDK + jb * 8);
-#pragma unroll
-                    for (int j = 0; j < TW; ++j)
-                        b8[jb][j] = *reinterpret_cast<const bf16x8*>(bp + j * 32 * LDK + jb * 8);
-                }
-#pragma unroll
-                for (int jb = 0; jb < BK / 16; ++jb)
-#pragma unroll
-                    for (int i = 0; i < TW; ++i)
-#pragma unroll
-                        for (int j = 0; j < TW; ++j)
-                            acc[jb % NC][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[jb][i], b8[jb][j],
-                                                                                         acc[jb % NC][i][j], 0, 0, 0);
-            } else {
-                // K order inside a step: lane half fk of block j holds k = 8j + 4fk + i for the i-th MFMA (any permutation
-                // of k is legal as long as A and B use the same one), so a lane's 4 values are ONE 16-byte LDS read per tile.
-                const float* ap = As + (wm * (BT / 2) + fr) * LDK + 4 * fk;
-                const float* bp = Bs + (wn * (BT / 2) + fr) * LDK + 4 * fk;
-                f32x4 a4[2][TW], b4[2][TW];
-    #pragma unroll
-                for (int i = 0; i < TW; ++i) a4[0][i] = *reinterpret_cast<const f32x4*>(ap + i * 32 * LDK);
-    #pragma unroll
-                for (int j = 0; j < TW; ++j) b4[0][j] = *reinterpret_cast<const f32x4*>(bp + j * 32 * LDK);
-    #pragma unroll
-                for (int jb = 0; jb < BK / 8; ++jb) {
-                    const int cur = jb & 1;
-                    if (jb + 1 < BK / 8) {  // fragments of the next 8-k block are in flight under this block's MFMAs
-    #pragma unroll
-                        for (int i = 0; i < TW; ++i)
-                            a4[cur ^ 1][i] = *reinterpret_cast<const f32x4*>(ap + i * 32 * LDK + (jb + 1) * 8);
-    #pragma unroll
-                        for (int j = 0; j < TW; ++j)
-                            b4[cur ^ 1][j] = *reinterpret_cast<const f32x4*>(bp + j * 32 * LDK + (jb + 1) * 8);
-                    }
-    #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-    #pragma unroll
-                        for (int i = 0; i < TW; ++i)
-    #pragma unroll
-                            for (int j = 0; j < TW; ++j)
-                                acc[e % NC][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[cur][i][e], b4[cur][j][e], acc[e % NC][i][j], 0,
-                                                                                 0, 0);
-                }
+            if (jb == NBLK - 1) {
+                // pin the order: this block's MFMAs stay BELOW the barrier and the reads behind it (left alone, the
+                // scheduler hoists the MFMAs above the barrier and the wave meets the LDS round trip with an empty pipe)
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                read_frags(An, An + TILE, 0, 0);  // block 0 of the next tile: lands under this block's MFMAs
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();
+            mfma_block(jb & 1);
+        }
+    };
+    // U steps per trip, a multiple of lcm(S, 2): hipcc's wait-count pass is exact inside the unrolled body but
+    // waits for ALL outstanding loads at the first LDS store after the loop header, so make trips long.
+    constexpr int U = g_unroll_mult * ((S % 2 == 0) ? S : 2 * S);
+    // step kt writes tile kt+1: unmasked while kt + 2 <= nfull
+    const int n_hot = nfull >= 2 ? ((nfull - 1) / U) * U : 0;
+    for (int kt0 = 0; kt0 < n_hot; kt0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) k_step(std::false_type{}, u, kt0 + u);
+    }
+    for (int kt0 = n_hot; kt0 < nk; kt0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (kt0 + u >= nk) break;  // block-uniform
+            k_step(std::true_type{}, u, kt0 + u);
         }
     }
 

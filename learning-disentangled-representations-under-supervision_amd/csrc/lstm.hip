@@ -326,6 +326,12 @@ __device__ __forceinline__ f32x4 ld4_sc1(__amdgpu_buffer_rsrc_t rsrc, int byte_o
     return __builtin_bit_cast(f32x4, v);
 }
 
+// the same with a wave-uniform (scalar) byte offset on top of the per-lane one
+__device__ __forceinline__ f32x4 ld4_sc1(__amdgpu_buffer_rsrc_t rsrc, int byte_off, int scalar_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, scalar_off, 16);  // aux 16 = sc1
+    return __builtin_bit_cast(f32x4, v);
+}
+
 __device__ __forceinline__ void st_sc1(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword ... sc1
 }
@@ -569,6 +575,348 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdPara
     if (evalid) sq.dc_state[(long)eb * H + ej] = dc_reg;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Two stacked layers in ONE persistent launch (the generator's nn.LSTM(num_layers=2), model/generator.py:17-20,58).
+//
+// Layer 1 of timestep t needs h0_t, layer 0 of timestep t+1 needs h0_t too: the two layers form a wavefront, layer 1
+// one timestep behind layer 0. Run back to back (round 1) each layer occupied half the chip for a whole sequence pass
+// and a time-batched x1·W_ih1ᵀ GEMM sat between them; here both layers' workgroups are resident together (2·NB·NJ <=
+// CUs) and layer 1's input projection moves INTO the recurrence: its workgroups multiply [h0_t ; h1_{t-1}] (K = 2H) with
+// their slice of [W_ih1 | W_hh1], resident in registers for the whole sequence like W_hh0 is for layer 0.
+// Hand-off: the same all-sc1 form as above, with one arrival counter per (layer, batch tile); a layer-1 workgroup waits
+// for its own group's step t-1 AND for layer 0's step t. Layer 0 never waits for layer 1 (the history buffers hold
+// every timestep), so it simply runs ahead.
+// Backward is the mirror image: the top layer's gate gradients of timestep t feed the bottom layer's dh0_t =
+// W_ih1ᵀ·dg1_t + W_hh0ᵀ·dg0_{t+1} (K = 8H, the dH0 GEMM of round 1 folded in), bottom one step behind top.
+// Zero initial state, forward direction, equal hidden sizes; final-state gradients are zero (the step discards the
+// generator's final state, model/cgn.py:1082).
+// ------------------------------------------------------------------------------------------------------------------
+struct Fwd2Params {
+    const float* xg0;
+    const float* xg0_extra;
+    const float* w_hh0;
+    const float* w_ih1;
+    const float* w_hh1;
+    const float* b_ih1;
+    const float* b_hh1;
+    float* hbuf[2];
+    float* cbuf[2];
+    float* gates[2];
+    int B, T, H;
+};
+
+// CPH: chunks (of 16 k) per wave and per operand half held in registers: H <= 128 * CPH. Every wave owns CPH chunks
+// of the h0_t half (layer 1 only; multiplied with W_ih1) and CPH chunks of the h_{t-1} half (W_hh), so that the two
+// halves can run as two PHASES of a timestep: layer 0 runs ahead of layer 1, its h0_t has long arrived, and the
+// W_ih1·h0_t half is done while this group's own step t-1 is still being handed over; only the W_hh1·h1_{t-1} half
+// (the same work as a single-layer step) sits behind the own-group wait.
+template <int CPH>
+__global__ __launch_bounds__(LSTM_NT) void lstm2_persist_fwd_kernel(const Fwd2Params p, unsigned* sync, unsigned* sticky) {
+    __shared__ float red[LSTM_NW][16][64];
+    __shared__ int s_ok;
+    const int B = p.B, T = p.T, H = p.H;
+    const int NJ = H / 16, NB = (B + 15) / 16;
+    const int wid = blockIdx.x;
+    const int layer = wid / (NB * NJ);
+    const int bt = (wid % (NB * NJ)) / NJ, jt = wid % NJ;
+    unsigned* cnt_own = sync + (layer * NB + bt) * SYNC_STRIDE;
+    unsigned* cnt_below = sync + bt * SYNC_STRIDE;  // layer 0's group of the same batch tile
+    unsigned* tmo = sync + 2 * NB * SYNC_STRIDE;
+    const int j0 = jt * 16, b0 = bt * 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: chunk ranges are wave-uniform
+    const int fr = lane & 15, q = lane >> 4;
+    const int nchunks = H / 16;                            // per half
+    const int cph = (nchunks + LSTM_NW - 1) / LSTM_NW;     // <= CPH (host check)
+    const int c_beg = wave * cph;
+    // chunk u of this wave covers columns colb(u) .. colb(u)+15 of the half's weight / operand rows; wave-uniform, so
+    // the chunk's byte offset travels as the SCALAR offset of the buffer loads (no per-chunk VGPRs)
+    auto chunk_ok = [&](int u) { return (u < cph) && (c_beg + u < nchunks); };
+    auto colb = [&](int u) { return chunk_ok(u) ? (c_beg + u) * 16 : 0; };
+
+    f32x4 w_lo[4][CPH], w_hi[4][CPH];  // [gate][chunk]: W_ih1 (layer 1 only) and W_hh slices, resident for all T steps
+    {
+        const float* w_own = layer ? p.w_hh1 : p.w_hh0;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < CPH; ++u) {
+            const bool ok = chunk_ok(u);
+            const long off = (long)(j0 + fr) * H + colb(u) + q * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 vh = ld4(w_own + (long)g * H * H + off);
+                w_hi[g][u] = ok ? vh : z;
+                if (layer) {
+                    const f32x4 vl = ld4(p.w_ih1 + (long)g * H * H + off);
+                    w_lo[g][u] = ok ? vl : z;
+                } else {
+                    w_lo[g][u] = z;
+                }
+            }
+        }
+    }
+    const int bA = min(b0 + fr, B - 1);
+    const int hbytes = B * (T + 1) * H * 4;
+    const __amdgpu_buffer_rsrc_t hres_own = __builtin_amdgcn_make_buffer_rsrc((void*)p.hbuf[layer], 0, hbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t hres_below = __builtin_amdgcn_make_buffer_rsrc((void*)p.hbuf[0], 0, hbytes, 0x00020000);
+
+    const int er = wave & 3;
+    const int eb = b0 + (lane >> 4) * 4 + er, ej = j0 + (lane & 15);
+    const int ebc = min(eb, B - 1);
+    const bool evalid = (wave < 4) && (eb < B);
+    float* hb = p.hbuf[layer];
+    float* cb = p.cbuf[layer];
+    float* gb = p.gates[layer];
+    if (evalid) {  // zero initial state: written for the later readers of the history buffers (dW_hh, backward)
+        hb[((long)eb * (T + 1)) * H + ej] = 0.f;
+        cb[((long)eb * (T + 1)) * H + ej] = 0.f;
+    }
+    float c_reg = 0.f;
+    float pre_c[4] = {0.f, 0.f, 0.f, 0.f};  // time-independent part of the pre-activations
+    if (layer == 0) {
+        if (p.xg0_extra) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre_c[g] = p.xg0_extra[(long)ebc * 4 * H + g * H + ej];
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre_c[g] = p.b_ih1[g * H + ej] + p.b_hh1[g * H + ej];
+    }
+
+    bool alive = true;
+    for (int t = 0; t < T && alive; ++t) {
+        float pre_x[4] = {0.f, 0.f, 0.f, 0.f};
+        if (layer == 0) {
+            const float* xg = p.xg0 + ((long)ebc * T + t) * 4 * H + ej;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre_x[g] = xg[g * H];
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = {0.f, 0.f, 0.f, 0.f};
+        // ---- phase A (layer 1): W_ih1 · h0_t; h0_t sits in slot t+1 of layer 0's history
+        if (layer == 1) {
+            if (threadIdx.x == 0) s_ok = group_wait(cnt_below, (unsigned)(NJ * (t + 1)), tmo, sticky) ? 1 : 0;
+            __syncthreads();
+            if (!s_ok) break;  // workgroup-uniform
+            const int off = (bA * (T + 1) + t + 1) * H * 4 + q * 16;
+            f32x4 a[CPH];
+#pragma unroll
+            for (int u = 0; u < CPH; ++u) a[u] = ld4_sc1(hres_below, off, colb(u) * 4);
+#pragma unroll
+            for (int u = 0; u < CPH; ++u) {  // chunks beyond this wave's range hold zero weights: no branch
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w_lo[g][u][i], acc[g], 0, 0, 0);
+                }
+            }
+            __syncthreads();  // s_ok is rewritten below
+        }
+        // ---- phase B: W_hh · h_{t-1} of this layer (slot t of its own history); h_{-1} = 0 contributes nothing
+        if (t > 0) {
+            if (threadIdx.x == 0) s_ok = group_wait(cnt_own, (unsigned)(NJ * t), tmo, sticky) ? 1 : 0;
+            __syncthreads();
+            if (!s_ok) break;  // workgroup-uniform
+            const int off = (bA * (T + 1) + t) * H * 4 + q * 16;
+            f32x4 a[CPH];
+#pragma unroll
+            for (int u = 0; u < CPH; ++u) a[u] = ld4_sc1(hres_own, off, colb(u) * 4);
+#pragma unroll
+            for (int u = 0; u < CPH; ++u) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w_hi[g][u][i], acc[g], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][g * 4 + r][lane] = acc[g][r];
+        __syncthreads();
+        if (evalid) {
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < LSTM_NW; ++wv) v += red[wv][g * 4 + er][lane];
+                pre[g] = v + pre_x[g] + pre_c[g];
+            }
+            const float ig = cgn_sigmoid(pre[0]);
+            const float fg = cgn_sigmoid(pre[1]);
+            const float gg = tanhf(pre[2]);
+            const float og = cgn_sigmoid(pre[3]);
+            const float cn = fg * c_reg + ig * gg;
+            const float hn = og * tanhf(cn);
+            c_reg = cn;
+            float* go = gb + ((long)eb * T + t) * 4 * H;
+            go[ej] = ig;
+            go[H + ej] = fg;
+            go[2 * H + ej] = gg;
+            go[3 * H + ej] = og;
+            cb[((long)eb * (T + 1) + t + 1) * H + ej] = cn;
+            st_sc1(hb + ((long)eb * (T + 1) + t + 1) * H + ej, hn);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the arrival is signalled
+        __syncthreads();
+        // layer 0 signals its last step too: layer 1's step T-1 waits for it
+        if (threadIdx.x == 0 && (layer == 0 || t + 1 < T))
+            __hip_atomic_fetch_add(cnt_own, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+struct Bwd2Params {
+    const float* w_hh0;
+    const float* w_ih1;
+    const float* w_hh1;
+    const float* cbuf[2];
+    const float* gates[2];
+    const float* dh_ext1;
+    float* dgates[2];
+    long dh_bs, dh_ts;
+    int B, T, H;
+};
+
+// role 0 = the TOP layer (layer 1: dh1_t = dH_ext[t] + W_hh1ᵀ·dg1_{t+1}), role 1 = the BOTTOM layer (layer 0:
+// dh0_t = W_ih1ᵀ·dg1_t + W_hh0ᵀ·dg0_{t+1}). CPH: chunks (of 16 k) per wave and per operand half held in registers:
+// 4H <= 128 * CPH. Two phases per timestep like the forward kernel: the W_ih1ᵀ·dg1_t half (the top layer runs ahead)
+// is done before this group's own previous step is waited for.
+template <int CPH>
+__global__ __launch_bounds__(LSTM_NT) void lstm2_persist_bwd_kernel(const Bwd2Params p, unsigned* sync, unsigned* sticky) {
+    __shared__ float red[LSTM_NW][4][64];
+    __shared__ int s_ok;
+    const int B = p.B, T = p.T, H = p.H;
+    const int K4 = 4 * H;
+    const int NJ = H / 16, NB = (B + 15) / 16;
+    const int wid = blockIdx.x;
+    const int role = wid / (NB * NJ);  // 0: layer 1 (top), 1: layer 0 (bottom)
+    const int layer = 1 - role;
+    const int bt = (wid % (NB * NJ)) / NJ, jt = wid % NJ;
+    unsigned* cnt_own = sync + (role * NB + bt) * SYNC_STRIDE;
+    unsigned* cnt_top = sync + bt * SYNC_STRIDE;
+    unsigned* tmo = sync + 2 * NB * SYNC_STRIDE;
+    const int j0 = jt * 16, b0 = bt * 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: chunk ranges are wave-uniform
+    const int fr = lane & 15, q = lane >> 4;
+    const int nchunks = K4 / 16;                           // per half
+    const int cph = (nchunks + LSTM_NW - 1) / LSTM_NW;     // <= CPH (host check)
+    const int c_beg = wave * cph;
+    auto chunk_ok = [&](int u) { return (u < cph) && (c_beg + u < nchunks); };
+    auto colb = [&](int u) { return chunk_ok(u) ? (c_beg + u) * 16 : 0; };  // scalar
+
+    // B operands = rows (j0 + fr) of W_ih1ᵀ (bottom layer only) and of this layer's W_hhᵀ, read once from the
+    // untransposed [4H,H] weights (16 lanes = 64 contiguous bytes per k)
+    f32x4 w_lo[CPH], w_hi[CPH];
+    {
+        const float* w_own = role ? p.w_hh0 : p.w_hh1;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < CPH; ++u) {
+            const bool ok = chunk_ok(u);
+            const int col = colb(u) + q * 4;
+            f32x4 vh, vl = z;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vh[i] = w_own[(long)(col + i) * H + j0 + fr];
+            if (role) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vl[i] = p.w_ih1[(long)(col + i) * H + j0 + fr];
+            }
+            w_hi[u] = ok ? vh : z;
+            w_lo[u] = ok ? vl : z;
+        }
+    }
+    const int bA = min(b0 + fr, B - 1);
+    const int dbytes = B * T * K4 * 4;
+    const __amdgpu_buffer_rsrc_t dres_own = __builtin_amdgcn_make_buffer_rsrc((void*)p.dgates[layer], 0, dbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dres_top = __builtin_amdgcn_make_buffer_rsrc((void*)p.dgates[1], 0, dbytes, 0x00020000);
+
+    const int er = wave & 3;
+    const int eb = b0 + (lane >> 4) * 4 + er, ej = j0 + (lane & 15);
+    const int ebc = min(eb, B - 1);
+    const bool evalid = (wave < 4) && (eb < B);
+    const float* gates = p.gates[layer];
+    const float* cbuf = p.cbuf[layer];
+    float* dgo = p.dgates[layer];
+    float dc_reg = 0.f;
+
+    for (int step = 0; step < T; ++step) {
+        const int t = T - 1 - step;
+        // operands of the gate-gradient update (written by earlier kernels): requested before the waits
+        const float* gt = gates + ((long)ebc * T + t) * K4 + ej;
+        const float ig = gt[0], fg = gt[H], gg = gt[2 * H], og = gt[3 * H];
+        const float cprev = cbuf[((long)ebc * (T + 1) + t) * H + ej];
+        const float cout = cbuf[((long)ebc * (T + 1) + t + 1) * H + ej];
+        const float dhx = role == 0 && p.dh_ext1 ? p.dh_ext1[(long)ebc * p.dh_bs + (long)t * p.dh_ts + ej] : 0.f;
+
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // ---- phase A (bottom layer): W_ih1ᵀ · dg1_t, the top layer's gate gradients of THIS timestep
+        if (role == 1) {
+            if (threadIdx.x == 0) s_ok = group_wait(cnt_top, (unsigned)(NJ * (step + 1)), tmo, sticky) ? 1 : 0;
+            __syncthreads();
+            if (!s_ok) break;  // workgroup-uniform
+            const int off = (bA * T + t) * K4 * 4 + q * 16;
+            f32x4 a[CPH];
+#pragma unroll
+            for (int u = 0; u < CPH; ++u) a[u] = ld4_sc1(dres_top, off, colb(u) * 4);
+#pragma unroll
+            for (int u = 0; u < CPH; u += 2) {  // chunks beyond this wave's range hold zero weights: no branch
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w_lo[u][i], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u + 1][i], w_lo[u + 1][i], acc1, 0, 0, 0);
+                }
+            }
+            __syncthreads();  // s_ok is rewritten below
+        }
+        // ---- phase B: W_hhᵀ · dg_{t+1} of this layer; the first step has none
+        if (step > 0) {
+            if (threadIdx.x == 0) s_ok = group_wait(cnt_own, (unsigned)(NJ * step), tmo, sticky) ? 1 : 0;
+            __syncthreads();
+            if (!s_ok) break;  // workgroup-uniform
+            const int off = (bA * T + t + 1) * K4 * 4 + q * 16;
+            f32x4 a[CPH];
+#pragma unroll
+            for (int u = 0; u < CPH; ++u) a[u] = ld4_sc1(dres_own, off, colb(u) * 4);
+#pragma unroll
+            for (int u = 0; u < CPH; u += 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w_hi[u][i], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u + 1][i], w_hi[u + 1][i], acc1, 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc0[r] + acc1[r];
+        __syncthreads();
+        if (evalid) {
+            float dh = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < LSTM_NW; ++wv) dh += red[wv][er][lane];
+            dh += dhx;
+            const float tc = tanhf(cout);
+            const float dc = dc_reg + dh * og * (1.f - tc * tc);
+            float* dg = dgo + ((long)eb * T + t) * K4;
+            st_sc1(dg + ej, dc * gg * ig * (1.f - ig));
+            st_sc1(dg + H + ej, dc * cprev * fg * (1.f - fg));
+            st_sc1(dg + 2 * H + ej, dc * ig * (1.f - gg * gg));
+            st_sc1(dg + 3 * H + ej, dh * tc * og * (1.f - og));
+            dc_reg = dc * fg;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // the top layer signals its last step too: the bottom layer's last step waits for it
+        if (threadIdx.x == 0 && (role == 0 || step + 1 < T))
+            __hip_atomic_fetch_add(cnt_own, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 int g_num_cus[16] = {0};
 
 int device_cus() {
@@ -597,6 +945,15 @@ long persist_zero_bytes(int nseq, int B) { return ((long)nseq * cgn_cdiv(B, 16) 
 long persist_sync_bytes(int nseq, int B) { return persist_zero_bytes(nseq, B) + SYNC_STRIDE * 4; }
 
 }  // namespace
+
+// two-layer wavefront form: both layers' workgroups resident together, the wider layer's weight slice in registers
+static bool persist2_ok(int B, int T, int H) {
+    if (B < 1 || T < 1 || H < 16 || H % 16 != 0 || H > 512) return false;
+    const long wgs = 2L * cgn_cdiv(B, 16) * (H / 16);
+    if (wgs > device_cus()) return false;
+    if ((long)B * (T + 1) * H * 4 >= (1L << 31) || (long)B * T * 4 * H * 4 >= (1L << 31)) return false;
+    return true;
+}
 
 extern "C" int cgn_lstm_seq_fwd_f32(void* stream, const cgn_lstm_fwd_seq* seqs, int32_t nseq, int32_t B, int32_t T,
                                     int32_t H) {
@@ -716,6 +1073,71 @@ extern "C" int cgn_lstm_seq_bwd_persistent_f32(void* stream, const cgn_lstm_bwd_
         hipLaunchKernelGGL((lstm_persist_bwd_kernel<8>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws, sticky);
     else
         hipLaunchKernelGGL((lstm_persist_bwd_kernel<16>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws, sticky);
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}
+
+extern "C" int cgn_lstm2_persistent_query(int32_t B, int32_t T, int32_t H, int64_t* sync_bytes) {
+    CGN_CHECK_ARG(sync_bytes != nullptr);
+    *sync_bytes = persist2_ok(B, T, H) ? persist_sync_bytes(2, B) : 0;
+    return CGN_OK;
+}
+
+extern "C" int cgn_lstm2_fwd_persistent_f32(void* stream, const cgn_lstm2_fwd* d, int32_t B, int32_t T, int32_t H,
+                                            void* sync_ws, int64_t sync_ws_bytes) {
+    CGN_CHECK_ARG(d != nullptr && B >= 0 && T >= 0 && H > 0);
+    if (B == 0 || T == 0) return CGN_OK;
+    CGN_CHECK_ARG(persist2_ok(B, T, H));
+    const long need = persist_sync_bytes(2, B);
+    CGN_CHECK_ARG(sync_ws && sync_ws_bytes >= need && ((uintptr_t)sync_ws % 16 == 0));
+    CGN_CHECK_ARG(d->xg0 && d->w_hh0 && d->w_ih1 && d->w_hh1 && d->b_ih1 && d->b_hh1);
+    CGN_CHECK_ARG(d->hbuf0 && d->cbuf0 && d->gates0 && d->hbuf1 && d->cbuf1 && d->gates1);
+    CGN_CHECK_ARG(((uintptr_t)d->hbuf0 % 16 == 0) && ((uintptr_t)d->hbuf1 % 16 == 0) && ((uintptr_t)d->w_hh0 % 16 == 0) &&
+                  ((uintptr_t)d->w_ih1 % 16 == 0) && ((uintptr_t)d->w_hh1 % 16 == 0));
+    Fwd2Params p;
+    p.xg0 = d->xg0; p.xg0_extra = d->xg0_extra; p.w_hh0 = d->w_hh0; p.w_ih1 = d->w_ih1; p.w_hh1 = d->w_hh1;
+    p.b_ih1 = d->b_ih1; p.b_hh1 = d->b_hh1;
+    p.hbuf[0] = d->hbuf0; p.cbuf[0] = d->cbuf0; p.gates[0] = d->gates0;
+    p.hbuf[1] = d->hbuf1; p.cbuf[1] = d->cbuf1; p.gates[1] = d->gates1;
+    p.B = B; p.T = T; p.H = H;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(sync_ws, 0, (size_t)persist_zero_bytes(2, B), st) != hipSuccess)
+        return CGN_ERR_HIP_BASE + (int)hipGetLastError();
+    unsigned* sticky = (unsigned*)((char*)sync_ws + (sync_ws_bytes / 128 - 1) * 128);
+    dim3 grid(2 * cgn_cdiv(B, 16) * (H / 16));
+    if (H <= 256)
+        hipLaunchKernelGGL((lstm2_persist_fwd_kernel<2>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws, sticky);
+    else
+        hipLaunchKernelGGL((lstm2_persist_fwd_kernel<4>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws, sticky);
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}
+
+extern "C" int cgn_lstm2_bwd_persistent_f32(void* stream, const cgn_lstm2_bwd* d, int32_t B, int32_t T, int32_t H,
+                                            void* sync_ws, int64_t sync_ws_bytes) {
+    CGN_CHECK_ARG(d != nullptr && B >= 0 && T >= 0 && H > 0);
+    if (B == 0 || T == 0) return CGN_OK;
+    CGN_CHECK_ARG(persist2_ok(B, T, H));
+    const long need = persist_sync_bytes(2, B);
+    CGN_CHECK_ARG(sync_ws && sync_ws_bytes >= need && ((uintptr_t)sync_ws % 16 == 0));
+    CGN_CHECK_ARG(d->w_hh0 && d->w_ih1 && d->w_hh1 && d->cbuf0 && d->gates0 && d->cbuf1 && d->gates1 && d->dgates0 &&
+                  d->dgates1);
+    CGN_CHECK_ARG(((uintptr_t)d->dgates0 % 16 == 0) && ((uintptr_t)d->dgates1 % 16 == 0));
+    Bwd2Params p;
+    p.w_hh0 = d->w_hh0; p.w_ih1 = d->w_ih1; p.w_hh1 = d->w_hh1;
+    p.cbuf[0] = d->cbuf0; p.gates[0] = d->gates0; p.cbuf[1] = d->cbuf1; p.gates[1] = d->gates1;
+    p.dh_ext1 = d->dh_ext1; p.dh_bs = d->dh_bs; p.dh_ts = d->dh_ts;
+    p.dgates[0] = d->dgates0; p.dgates[1] = d->dgates1;
+    p.B = B; p.T = T; p.H = H;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(sync_ws, 0, (size_t)persist_zero_bytes(2, B), st) != hipSuccess)
+        return CGN_ERR_HIP_BASE + (int)hipGetLastError();
+    unsigned* sticky = (unsigned*)((char*)sync_ws + (sync_ws_bytes / 128 - 1) * 128);
+    dim3 grid(2 * cgn_cdiv(B, 16) * (H / 16));
+    if (H <= 256)
+        hipLaunchKernelGGL((lstm2_persist_bwd_kernel<8>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws, sticky);
+    else
+        hipLaunchKernelGGL((lstm2_persist_bwd_kernel<16>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws, sticky);
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }

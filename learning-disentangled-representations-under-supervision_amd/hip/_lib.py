@@ -60,6 +60,16 @@ class LstmBwdSeq(C.Structure):
                 ("dgates", c_ptr), ("dc_state", c_ptr), ("dh_bs", c_i64), ("dh_ts", c_i64), ("reverse", c_i32)]
 
 
+class Lstm2Fwd(C.Structure):
+    _fields_ = [(n, c_ptr) for n in ("xg0", "xg0_extra", "w_hh0", "w_ih1", "w_hh1", "b_ih1", "b_hh1", "hbuf0", "cbuf0",
+                                     "gates0", "hbuf1", "cbuf1", "gates1")]
+
+
+class Lstm2Bwd(C.Structure):
+    _fields_ = [(n, c_ptr) for n in ("w_hh0", "w_ih1", "w_hh1", "cbuf0", "gates0", "cbuf1", "gates1", "dh_ext1",
+                                     "dgates0", "dgates1")] + [("dh_bs", c_i64), ("dh_ts", c_i64)]
+
+
 class ConvWidths(C.Structure):
     _fields_ = [("W", c_ptr * 8), ("dW", c_ptr * 8), ("db", c_ptr * 8),
                 ("K", c_i32 * 8), ("Co", c_i32 * 8), ("col0", c_i32 * 8),
@@ -84,6 +94,9 @@ PROTOTYPES = {
     "cgn_lstm_persistent_query": (c_i32, [c_i32, c_i32, c_i32, c_i32, C.POINTER(c_i64)]),
     "cgn_lstm_seq_fwd_persistent_f32": (c_i32, [c_ptr, C.POINTER(LstmFwdSeq), c_i32, c_i32, c_i32, c_i32, c_ptr, c_i64]),
     "cgn_lstm_seq_bwd_persistent_f32": (c_i32, [c_ptr, C.POINTER(LstmBwdSeq), c_i32, c_i32, c_i32, c_i32, c_ptr, c_i64]),
+    "cgn_lstm2_persistent_query": (c_i32, [c_i32, c_i32, c_i32, C.POINTER(c_i64)]),
+    "cgn_lstm2_fwd_persistent_f32": (c_i32, [c_ptr, C.POINTER(Lstm2Fwd), c_i32, c_i32, c_i32, c_ptr, c_i64]),
+    "cgn_lstm2_bwd_persistent_f32": (c_i32, [c_ptr, C.POINTER(Lstm2Bwd), c_i32, c_i32, c_i32, c_ptr, c_i64]),
     "cgn_beam_topk_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr,
                                   c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "cgn_act_maxpool_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr, c_i64, c_i32, c_ptr, c_i64]),

@@ -133,13 +133,13 @@ def highway_fwd(x, layers):
     return x, saved
 
 
-def highway_bwd(saved, layers, dy, grads, need_dx, beta=0.0, side=None):
+def highway_bwd(saved, layers, dy, grads, need_dx, beta=0.0, later=None):
     """grads: list of dict(nw, nb, lw, lb, gw, gb[, wcat, bcat]) gradient tensors (may be None to skip parameter
-    grads). side: optional context-manager factory; the parameter-gradient GEMMs run inside it (a side stream).
+    grads). later: optional callable(fn) that runs the parameter-gradient work fn() now or later, on another stream
+    (CGNStep.later); default: at once.
     The gate backward writes zeros into the pad columns of dpre, so the stacked forms (one dW GEMM, one column sum,
     one dX GEMM over K = 3*Sp) see exact zeros for the pad rows of wcat."""
-    import contextlib
-    side = side or contextlib.nullcontext
+    later = later or (lambda fn: fn())
     dx = None
     for li in range(len(layers) - 1, -1, -1):
         x, pre = saved[li]
@@ -151,7 +151,8 @@ def highway_bwd(saved, layers, dy, grads, need_dx, beta=0.0, side=None):
         views = (dpre[:, 0:S], dpre[:, Sp:Sp + S], dpre[:, 2 * Sp:2 * Sp + S])
         if grads is not None:
             g = grads[li]
-            with side():
+
+            def param_grads(g=g, dpre=dpre, x=x, views=views):
                 if g.get("wcat") is not None:
                     ops.gemm(dpre.t(), x, g["wcat"], beta=beta)
                     ops.colsum(dpre, g["bcat"], beta=beta)
@@ -159,6 +160,8 @@ def highway_bwd(saved, layers, dy, grads, need_dx, beta=0.0, side=None):
                     for v, wn, bn in zip(views, ("nw", "lw", "gw"), ("nb", "lb", "gb")):
                         ops.gemm(v.t(), x, g[wn], beta=beta)
                         ops.colsum(v, g[bn], beta=beta)
+
+            later(param_grads)
         if li > 0 or need_dx:
             dx = ops.new2d(N, S, x.device)
             if p.get("wcat") is not None:
@@ -177,9 +180,9 @@ def highway_bwd(saved, layers, dy, grads, need_dx, beta=0.0, side=None):
 class LstmSeq:
     """One direction of one layer: buffers + addressing helpers."""
 
-    def __init__(self, B, T, H, dev, reverse):
+    def __init__(self, B, T, H, dev, reverse, need_xg=True):
         self.B, self.T, self.H, self.reverse = B, T, H, reverse
-        self.xg = _new((B, T, 4 * H), dev)
+        self.xg = _new((B, T, 4 * H), dev) if need_xg else None  # layer 1 of a fused two-layer launch has none
         self.hbuf = _new((B, T + 1, H), dev)
         self.cbuf = _new((B, T + 1, H), dev)
         self.gates = _new((B, T, 4 * H), dev)

@@ -19,6 +19,8 @@ next segment. The collectives themselves are never captured (nothing here depend
 segmentation keeps is the one-launch-per-segment host cost and the overlap: the generator's gradient all-reduce
 travels while the encoder-backward segment runs, the encoder's while the generator's Adam segment runs.
 """
+import warnings
+
 import torch
 
 from . import ops
@@ -60,8 +62,83 @@ class _SegmentRecorder:
             self.g = None
 
 
+class _BranchRecorder:
+    """Captures one pass of the step as ONE hipGraph PER BRANCH: the main chain is cut wherever a side region begins or
+    a side stream is joined, and every side region (CGNStep.side) becomes a graph of its own. A replay launches the
+    graphs in recorded order, main graphs on the caller's stream, side graphs on explicit side streams, with events for
+    the fork ("behind everything the main stream was given so far") and the join.
+
+    Why not one graph with internal branches (round 1): which hardware queue ROCm gives a graph-internal branch is not
+    under the program's control, and with HIP's 4 hardware queues per process two branches regularly shared one and
+    simply ran one after the other (profiles/r02: the discriminator step never overlapped the encoder forward, the
+    generator's parameter gradients never overlapped the encoder's dX chain). Explicit streams make the overlap the
+    program's decision; the graphs share one memory pool and every temporary of the recorded step is kept alive
+    (ops.KEEP), so graphs that run side by side never alias memory."""
+
+    parallel = True
+
+    def __init__(self, main_stream, thread_local):
+        self.main_stream = main_stream
+        self.pool = torch.cuda.graph_pool_handle()
+        self.kw = dict(capture_error_mode="thread_local") if thread_local else {}
+        self.segments = []   # ("main", graph, [side streams to wait for first]) | ("side", graph, k)
+        self.g = None        # main graph being captured
+        self.waits = []      # joins that the NEXT main graph starts with
+        self.side_g = None
+
+    def _begin_main(self):
+        self.g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(self.main_stream):
+            self.g.capture_begin(pool=self.pool, **self.kw)
+
+    def _end_main(self):
+        if self.g is not None:
+            with torch.cuda.stream(self.main_stream), warnings.catch_warnings():
+                # a join right behind a fork leaves nothing between them: torch warns about the empty graph
+                warnings.filterwarnings("ignore", message="The CUDA Graph is empty")
+                self.g.capture_end()
+            self.segments.append(("main", self.g, self.waits))
+            self.g, self.waits = None, []
+
+    def begin(self):
+        self._begin_main()
+
+    def begin_side(self, k, stream):
+        self._end_main()
+        self.side_g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(stream):
+            self.side_g.capture_begin(pool=self.pool, **self.kw)
+        self._side_stream = stream
+
+    def end_side(self, k):
+        with torch.cuda.stream(self._side_stream):
+            self.side_g.capture_end()
+        self.segments.append(("side", self.side_g, k))
+        self.side_g = None
+        self._begin_main()
+
+    def join(self, k):
+        self._end_main()
+        self.waits.append(k)
+        self._begin_main()
+
+    def end(self):
+        self._end_main()
+
+    def abort(self):
+        for g, st in ((self.side_g, getattr(self, "_side_stream", None)), (self.g, self.main_stream)):
+            if g is not None:
+                try:
+                    with torch.cuda.stream(st):
+                        g.capture_end()
+                except Exception:
+                    pass
+        self.g = self.side_g = None
+
+
 class GraphedWakeSleep:
-    def __init__(self, eng, opts, data, calc_z_loss=False, overlap=True, warmup_kld=0.5, warmup_tau=1.0):
+    def __init__(self, eng, opts, data, calc_z_loss=False, overlap=True, warmup_kld=0.5, warmup_tau=1.0,
+                 branch_graphs=True):
         """eng: CGNStep; opts: dict(disc, enc, gen) of AdamState; data: dict of device tensors giving the SHAPES of
         every later batch (their current contents are used for ONE real warm-up step, which trains the model like any
         other step)."""
@@ -72,6 +149,7 @@ class GraphedWakeSleep:
         # ring of pinned scalar blocks: the async H2D copy of step n may still be queued when the host prepares n+1
         self.pinned = torch.zeros(256, 4, dtype=torch.float32).pin_memory()
         self.calls = 0
+        self.branches = None  # per-branch graphs (single-GPU overlapped replay), see _BranchRecorder
         self.stream = torch.cuda.Stream(eng.dev)
         self.graph = torch.cuda.CUDAGraph()
         for st in opts.values():
@@ -116,6 +194,25 @@ class GraphedWakeSleep:
                     finally:
                         eng.recorder = None
                     self.segments = rec.segments
+                elif overlap and branch_graphs:
+                    import gc
+                    gc.collect()
+                    torch.cuda.empty_cache()
+                    rec = _BranchRecorder(self.stream, thread_local=torch.distributed.is_initialized())
+                    eng.recorder = rec
+                    try:
+                        rec.begin()
+                        try:
+                            with torch.cuda.stream(self.stream):
+                                self.out = self._run()
+                            rec.end()
+                        except BaseException:
+                            rec.abort()
+                            raise
+                    finally:
+                        eng.recorder = None
+                    self.branches = rec.segments
+                    self.segments = None
                 else:
                     with torch.cuda.graph(self.graph, stream=self.stream):
                         self.out = self._run()
@@ -124,6 +221,45 @@ class GraphedWakeSleep:
                 self.keep, ops.KEEP = ops.KEEP, None  # temporaries of the captured step stay alive with the graph
         finally:
             eng.overlap, eng.dynamic = prev
+
+    def _replay_branches(self):
+        """Main graphs on the current stream, side graphs on the engine's side streams; a side graph starts behind
+        everything the main stream has been given so far, a main graph that follows a join waits for that side stream.
+        The host hands the main graph that FOLLOWS a fork to the GPU before the side graphs of that fork (the fork
+        event is recorded where the step forks, so the order on the device is the recorded one): the main chain is the
+        critical path and should never wait for the host to finish launching side work."""
+        eng = self.eng
+        main = torch.cuda.current_stream(eng.dev)
+        sides = eng._side_streams
+        done, held = {}, []
+
+        def launch_sides():
+            for g, k, fork in held:
+                st = sides[k]
+                st.wait_event(fork)
+                with torch.cuda.stream(st):
+                    g.replay()
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                done[k] = ev
+            del held[:]
+
+        for kind, g, arg in self.branches:
+            if kind == "main":
+                if arg:
+                    launch_sides()
+                    for k in arg:
+                        if k in done:
+                            main.wait_event(done.pop(k))
+                g.replay()
+                launch_sides()
+            else:
+                fork = torch.cuda.Event()
+                fork.record(main)
+                held.append((g, arg, fork))
+        launch_sides()
+        for ev in done.values():  # nothing of this step may still run when the caller's stream moves on
+            main.wait_event(ev)
 
     def _slot(self):
         self.calls += 1
@@ -150,13 +286,15 @@ class GraphedWakeSleep:
         if data is not None:
             self.load(data)
         eng.set_step_scalars(kld_coeff, temperature, self.NT, self.B, self._slot())
-        for i, (g, actions) in enumerate(self.segments):
+        if self.branches is not None:
+            self._replay_branches()
+        for i, (g, actions) in enumerate(self.segments or ()):
             self.progress = (self.calls, i, "replay")
             g.replay()
             for kind, group in actions:
                 self.progress = (self.calls, i, kind + " " + group)
                 eng.do_comm(kind, group)
-        self.progress = (self.calls, len(self.segments), "done")
+        self.progress = (self.calls, len(self.segments or ()), "done")
         self._bump_host_steps()
         d_losses, c, eg = self.out
         ce, kld, z_loss, c_loss = eg[:4]

@@ -675,6 +675,63 @@ def lstm_seq_bwd(seqs, B, T, H):
         _call("cgn_lstm_seq_bwd_f32", dev, arr, len(seqs), B, T, H)
 
 
+LSTM_FUSE_LAYERS = _os.environ.get("CGN_LSTM_FUSE_LAYERS", "1") != "0"
+
+
+def lstm2_persistent_bytes(B, T, H, dev):
+    """Scratch bytes of the two-layer wavefront launch for this shape on `dev`; 0 = not eligible (or switched off)."""
+    if not (LSTM_PERSISTENT and LSTM_FUSE_LAYERS):
+        return 0
+    n = C.c_int64(0)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().cgn_lstm2_persistent_query(B, T, H, C.byref(n)), "cgn_lstm2_persistent_query")
+    return n.value if n.value <= LSTM_SYNC_BYTES else 0
+
+
+def _chk_shape(t, shape, name):
+    _chk_f32(t, name)
+    _req(t.is_contiguous() and tuple(t.shape) == tuple(shape), "lstm2 %s must be contiguous %s" % (name, tuple(shape)))
+
+
+def lstm2_fwd(xg0, xg0_extra, w_hh0, w_ih1, w_hh1, b_ih1, b_hh1, hbuf0, cbuf0, gates0, hbuf1, cbuf1, gates1, B, T, H):
+    """Both layers of a two-layer LSTM (zero initial state) in one persistent launch (cgn_lstm2_fwd_persistent_f32)."""
+    dev = hbuf0.device
+    _req(lstm2_persistent_bytes(B, T, H, dev) > 0, "shape not eligible for the two-layer launch")
+    d = _lib.Lstm2Fwd()
+    for name, t, shape in (("xg0", xg0, (B, T, 4 * H)), ("w_hh0", w_hh0, (4 * H, H)), ("w_ih1", w_ih1, (4 * H, H)),
+                           ("w_hh1", w_hh1, (4 * H, H)), ("b_ih1", b_ih1, (4 * H,)), ("b_hh1", b_hh1, (4 * H,)),
+                           ("hbuf0", hbuf0, (B, T + 1, H)), ("cbuf0", cbuf0, (B, T + 1, H)),
+                           ("gates0", gates0, (B, T, 4 * H)), ("hbuf1", hbuf1, (B, T + 1, H)),
+                           ("cbuf1", cbuf1, (B, T + 1, H)), ("gates1", gates1, (B, T, 4 * H))):
+        _chk_shape(t, shape, name)
+        setattr(d, name, t.data_ptr())
+    if xg0_extra is not None:
+        _chk_shape(xg0_extra, (B, 4 * H), "xg0_extra")
+        d.xg0_extra = xg0_extra.data_ptr()
+    ws = _lstm_sync_ws(dev)
+    _call("cgn_lstm2_fwd_persistent_f32", dev, C.byref(d), B, T, H, _ptr(ws), ws.numel() * 4)
+
+
+def lstm2_bwd(w_hh0, w_ih1, w_hh1, cbuf0, gates0, cbuf1, gates1, dh_ext1, dh_bs, dh_ts, dgates0, dgates1, B, T, H):
+    """BPTT through both layers in one persistent launch (cgn_lstm2_bwd_persistent_f32)."""
+    dev = dgates0.device
+    _req(lstm2_persistent_bytes(B, T, H, dev) > 0, "shape not eligible for the two-layer launch")
+    d = _lib.Lstm2Bwd()
+    for name, t, shape in (("w_hh0", w_hh0, (4 * H, H)), ("w_ih1", w_ih1, (4 * H, H)), ("w_hh1", w_hh1, (4 * H, H)),
+                           ("cbuf0", cbuf0, (B, T + 1, H)), ("gates0", gates0, (B, T, 4 * H)),
+                           ("cbuf1", cbuf1, (B, T + 1, H)), ("gates1", gates1, (B, T, 4 * H)),
+                           ("dgates0", dgates0, (B, T, 4 * H)), ("dgates1", dgates1, (B, T, 4 * H))):
+        _chk_shape(t, shape, name)
+        setattr(d, name, t.data_ptr())
+    if dh_ext1 is not None:
+        _chk_f32(dh_ext1, "dh_ext1")
+        nelem = dh_ext1.untyped_storage().nbytes() // 4 - dh_ext1.storage_offset()
+        _req(dh_bs >= 0 and dh_ts >= 0 and (B - 1) * dh_bs + (T - 1) * dh_ts + H <= nelem, "dh_ext1 addressing out of range")
+        d.dh_ext1, d.dh_bs, d.dh_ts = dh_ext1.data_ptr(), int(dh_bs), int(dh_ts)
+    ws = _lstm_sync_ws(dev)
+    _call("cgn_lstm2_bwd_persistent_f32", dev, C.byref(d), B, T, H, _ptr(ws), ws.numel() * 4)
+
+
 def lincomb(terms, out=None):
     """out[0] = sum coef*src[0] over terms [(coef, tensor), ...] (<= 4): scalar loss totals, on device."""
     n = len(terms)

@@ -11,6 +11,7 @@ reference's step closures (model/cgn.py:269-341 and :1049-1154; SURVEY.md §8a-1
 Parameter gradients land in the flat arenas (hip/arena.py); one Adam kernel per optimizer group.
 """
 import contextlib
+import os
 
 import torch
 
@@ -86,6 +87,8 @@ class CGNStep:
         self.overlap = False
         self._side_streams = None
         self._dirty = set()
+        self._deferring = False
+        self._deferred = []
         # Device-resident step scalars {1/tau, 79/(tau*B*T), kld_coef/B, kld_coef}: when `dynamic` the kernels read these
         # instead of immediates baked into their arguments, and Adam reads a device step count, so that a captured
         # graph can be replayed while the schedules (utils/functional.py:28-42) advance.
@@ -112,6 +115,18 @@ class CGNStep:
         if self._side_streams is None:
             self._side_streams = [torch.cuda.Stream(self.dev) for _ in range(2)]
         st = self._side_streams[k]
+        rec = self.recorder
+        if rec is not None and getattr(rec, "parallel", False):
+            # recording the step as one hipGraph PER BRANCH (hip/graph.py _BranchRecorder): the region becomes a graph
+            # of its own, replayed on side stream k behind everything the main stream was given so far
+            rec.begin_side(k, st)
+            self._dirty.add(k)
+            try:
+                with torch.cuda.stream(st):
+                    yield
+            finally:
+                rec.end_side(k)
+            return
         ev = torch.cuda.Event()
         ev.record()
         st.wait_event(ev)
@@ -120,12 +135,52 @@ class CGNStep:
             yield
 
     def join(self, *ks):
+        rec = self.recorder
         for k in ks:
             if k in self._dirty:
-                ev = torch.cuda.Event()
-                ev.record(self._side_streams[k])
-                torch.cuda.current_stream(self.dev).wait_event(ev)
+                if rec is not None and getattr(rec, "parallel", False):
+                    rec.join(k)  # the main branch is cut here: what follows waits for side stream k
+                else:
+                    ev = torch.cuda.Event()
+                    ev.record(self._side_streams[k])
+                    torch.cuda.current_stream(self.dev).wait_event(ev)
                 self._dirty.discard(k)
+
+    # Scheduling of the overlapped (captured) step. Measured on MI355X (profiles/r02_*): a persistent LSTM launch needs
+    # its workgroups resident together and holds most of a CU's registers, so a GEMM that shares the chip with it either
+    # keeps its workgroups waiting for CUs (the launch then takes 2-3x as long) or cannot get on a CU at all. So:
+    #   * exclusive(): every persistent LSTM launch starts with the side streams joined - it runs alone;
+    #   * later(k, fn): parameter-gradient work that nothing on the critical path needs is not forked where its inputs
+    #     become ready (that would put it beside the next LSTM launch) but queued, and flush() forks all of it behind
+    #     the LAST LSTM launch of the step, spread over the side streams, where it overlaps the dX chain's GEMMs.
+    # Eager mode (overlap off), data-parallel runs (gradients are wanted early for the all-reduce) and capture (tests
+    # read gradients at fixed points) run later() at once.
+    def exclusive(self):
+        if self.overlap and not self.dp:
+            self.join(0, 1)
+
+    def later(self, k, fn):
+        if self._deferring:
+            self._deferred.append((k, fn))
+        else:
+            with self.side(k):
+                fn()
+
+    def begin_defer(self, capture):
+        self._deferring = bool(self.overlap and not self.dp and capture is None)
+
+    def flush(self, only=None):
+        """Fork the queued work now. only=k: just side stream k's share (the rest stays queued, and later() keeps
+        queueing for the other streams until a flush without `only`)."""
+        todo = [(k, fn) for k, fn in self._deferred if only is None or k == only]
+        self._deferred = [(k, fn) for k, fn in self._deferred if not (only is None or k == only)]
+        if only is None:
+            self._deferring = False
+        for k in sorted({k for k, _ in todo}, reverse=True):  # one region (one branch graph) per side stream
+            with self.side(k):
+                for kk, fn in todo:
+                    if kk == k:
+                        fn()
 
     @contextlib.contextmanager
     def keepalive(self):
@@ -310,6 +365,7 @@ class CGNStep:
             ops.gemm(hw_out, P["encoder.rnn.weight_ih_l0" + sfx].t(), s.xg.view(N, 4 * He),
                      bias0=P["encoder.rnn.bias_ih_l0" + sfx], bias1=P["encoder.rnn.bias_hh_l0" + sfx])
             s.set_initial()
+        self.exclusive()
         engine.lstm_run_fwd([sf, sr], [P["encoder.rnn.weight_hh_l0"], P["encoder.rnn.weight_hh_l0_reverse"]])
         ctx = _new((B, 2 * He), self.dev)
         ops.copy2d(sf.c_final(), ctx[:, :He])
@@ -335,36 +391,47 @@ class CGNStep:
         dmu, dlv = dmulv[:, :Z], dmulv[:, Z:]
         w2 = self._fused("e2.w", P)
         if w2 is not None:
+            ops.gemm(dmulv, w2, dctx)
             if param_grads:
-                engine.linear_bwd(ctx, w2, dmulv, self._fused("e2.w", G), self._fused("e2.b", G), dx=dctx)
-            else:
-                ops.gemm(dmulv, w2, dctx)
-        elif param_grads:
-            engine.linear_bwd(ctx, P["e2mu.weight"], dmu, G["e2mu.weight"], G["e2mu.bias"], dx=dctx)
-            engine.linear_bwd(ctx, P["e2logvar.weight"], dlv, G["e2logvar.weight"], G["e2logvar.bias"], dx=dctx,
-                              dx_beta=1.0)
+                self.later(0, lambda: engine.linear_bwd(ctx, w2, dmulv, self._fused("e2.w", G), self._fused("e2.b", G)))
         else:
             ops.gemm(dmu, P["e2mu.weight"], dctx)
             ops.gemm(dlv, P["e2logvar.weight"], dctx, beta=1.0)
+            if param_grads:
+                self.later(0, lambda: (engine.linear_bwd(ctx, P["e2mu.weight"], dmu, G["e2mu.weight"], G["e2mu.bias"]),
+                                       engine.linear_bwd(ctx, P["e2logvar.weight"], dlv, G["e2logvar.weight"],
+                                                         G["e2logvar.bias"])))
         dcf, dcr = _new((B, He), self.dev), _new((B, He), self.dev)
         ops.copy2d(dctx[:, :He], dcf)
         ops.copy2d(dctx[:, He:], dcr)
         sf, sr = es["sf"], es["sr"]
+        self.exclusive()
         dgf, dgr = engine.lstm_run_bwd([sf, sr], [P["encoder.rnn.weight_hh_l0"], P["encoder.rnn.weight_hh_l0_reverse"]],
                                        [None, None], [None, None], [dcf, dcr])
         hw_out = es["hw_out"]
         Din = hw_out.shape[1]
+        if param_grads:
+            # parameter gradients leave the critical path (dX chain) when streams overlap
+            for s, dg, sfx in ((sf, dgf, ""), (sr, dgr, "_reverse")):
+                self.later(0, lambda s=s, dg=dg, sfx=sfx: engine.lstm_param_grads(
+                    s, dg, (hw_out, Axis(hw_out.stride(0), 0, 0)), G["encoder.rnn.weight_ih_l0" + sfx],
+                    G["encoder.rnn.weight_hh_l0" + sfx], G["encoder.rnn.bias_ih_l0" + sfx],
+                    G["encoder.rnn.bias_hh_l0" + sfx]))
+            # The step's last LSTM launch is behind us: what later() queued forks here. (Inside ONE captured graph a node
+            # with three successors - main and both side streams - replayed wrongly on ROCm 7.2: the dX GEMM below ran
+            # on unfinished LSTM gradients (tools/graph_diff.py). The in-graph form therefore forks side stream 1 here
+            # and side stream 0 one kernel further down; the per-branch graphs of hip/graph.py have no such node.)
+            staggered = self.overlap and not getattr(self.recorder, "parallel", False)
+            self.flush(only=1 if staggered else None)
         dhw = ops.new2d(N, Din, self.dev)
-        for i, (s, dg, sfx) in enumerate(((sf, dgf, ""), (sr, dgr, "_reverse"))):
-            if param_grads:
-                with self.side(1):  # parameter gradients leave the critical path (dX chain) when streams overlap
-                    engine.lstm_param_grads(s, dg, (hw_out, Axis(hw_out.stride(0), 0, 0)),
-                                            G["encoder.rnn.weight_ih_l0" + sfx], G["encoder.rnn.weight_hh_l0" + sfx],
-                                            G["encoder.rnn.bias_ih_l0" + sfx], G["encoder.rnn.bias_hh_l0" + sfx])
-            dg2 = dg.view(N, 4 * He)
-            ops.gemm(dg2, P["encoder.rnn.weight_ih_l0" + sfx], dhw, beta=(0.0 if i == 0 else 1.0))
+        for i, (dg, sfx) in enumerate(((dgf, ""), (dgr, "_reverse"))):
+            ops.gemm(dg.view(N, 4 * He), P["encoder.rnn.weight_ih_l0" + sfx], dhw, beta=(0.0 if i == 0 else 1.0))
+            if param_grads and i == 0:
+                self.flush()
+        if param_grads and self.overlap and not self.dp and getattr(self.recorder, "parallel", False):
+            self._deferring = True  # the highway's dW products wait for the end of the dX chain (one more branch graph)
         return engine.highway_bwd(es["hw_saved"], self._hw_layers(P), dhw, self._hw_layers(G) if param_grads else None,
-                                  need_dx=True, side=lambda: self.side(1))
+                                  need_dx=True, later=lambda fn: self.later(0, fn))
 
     def total_losses(self, ce, kld, c_loss, z_loss, kld_coeff, use_disc=True, calc_z_loss=False):
         """total_encoder_loss, total_generator_loss of cgn.py:1151-1152 from their parts (device scalars)."""
@@ -450,8 +517,9 @@ class CGNStep:
         _cap_sel(capture, "enc/tdnn", tsaved["arg"])
         # ---- encode_for_z (cgn.py:83-103) + KLD (:1076) + [z,c] (:1080) ------------------------------------------
         es = self._encoder_fwd(enc_in, B, L)
-        for l, (_, pre) in enumerate(es["hw_saved"]):
-            _cap_sel(capture, "enc/hw%d" % l, pre[:, :Din] > 0)
+        if capture is not None:
+            for l, (_, pre) in enumerate(es["hw_saved"]):
+                _cap_sel(capture, "enc/hw%d" % l, pre[:, :Din] > 0)
         mulv = es["mulv"]
         zc, std, kld = _new((B, Z + C), dev), _new((B, Z), dev), _new((1,), dev)
         if callable(c_target):
@@ -463,7 +531,11 @@ class CGNStep:
         gen_emb = _new((NT, E), dev)
         ops.gather_rows(table, dec_word.reshape(-1), gen_emb,
                         mask=None if gen_drop_mask is None else gen_drop_mask.reshape(NT, E))
-        g0, g1 = engine.LstmSeq(B, T, Hg, dev, False), engine.LstmSeq(B, T, Hg, dev, False)
+        # both layers in one wavefront launch when the shape allows (csrc/lstm.hip lstm2_*): layer 1 needs no xg then
+        fuse2 = (cfg.decoder_num_layers == 2 and ops.lstm2_persistent_bytes(B, T, Hg, dev) > 0
+                 and all(P["generator.rnn.%s_l%d" % (k, l)].is_contiguous() for k in ("weight_hh",) for l in (0, 1))
+                 and P["generator.rnn.weight_ih_l1"].is_contiguous())
+        g0, g1 = engine.LstmSeq(B, T, Hg, dev, False), engine.LstmSeq(B, T, Hg, dev, False, need_xg=not fuse2)
         Wih0 = P["generator.rnn.weight_ih_l0"]
         ops.gemm(gen_emb, Wih0[:, :E].t(), g0.xg.view(NT, 4 * Hg), bias0=P["generator.rnn.bias_ih_l0"],
                  bias1=P["generator.rnn.bias_hh_l0"])
@@ -471,12 +543,19 @@ class CGNStep:
         ops.gemm(zc, Wih0[:, E:].t(), zg)  # the tiled [z,c] input contributes once per sentence
         g0.xg_extra = zg
         g0.set_initial()
-        engine.lstm_run_fwd([g0], [P["generator.rnn.weight_hh_l0"]])
-        h0, h0ax = g0.hout_operand()
-        ops.gemm(h0, P["generator.rnn.weight_ih_l1"].t(), g1.xg.view(NT, 4 * Hg), M=NT, K=Hg, a_m=h0ax, a_k=LIN,
-                 bias0=P["generator.rnn.bias_ih_l1"], bias1=P["generator.rnn.bias_hh_l1"])
         g1.set_initial()
-        engine.lstm_run_fwd([g1], [P["generator.rnn.weight_hh_l1"]])
+        self.exclusive()
+        if fuse2:
+            ops.lstm2_fwd(g0.xg, zg, P["generator.rnn.weight_hh_l0"], P["generator.rnn.weight_ih_l1"],
+                          P["generator.rnn.weight_hh_l1"], P["generator.rnn.bias_ih_l1"], P["generator.rnn.bias_hh_l1"],
+                          g0.hbuf, g0.cbuf, g0.gates, g1.hbuf, g1.cbuf, g1.gates, B, T, Hg)
+            h0, h0ax = g0.hout_operand()
+        else:
+            engine.lstm_run_fwd([g0], [P["generator.rnn.weight_hh_l0"]])
+            h0, h0ax = g0.hout_operand()
+            ops.gemm(h0, P["generator.rnn.weight_ih_l1"].t(), g1.xg.view(NT, 4 * Hg), M=NT, K=Hg, a_m=h0ax, a_k=LIN,
+                     bias0=P["generator.rnn.bias_ih_l1"], bias1=P["generator.rnn.bias_hh_l1"])
+            engine.lstm_run_fwd([g1], [P["generator.rnn.weight_hh_l1"]])
         h1, h1ax = g1.hout_operand()
         logits = _new((NT, V), dev)
         ops.gemm(h1, P["generator.fc.weight"].t(), logits, M=NT, K=Hg, a_m=h1ax, a_k=LIN, bias0=P["generator.fc.bias"])
@@ -521,8 +600,9 @@ class CGNStep:
             ops.copy3d(out_emb.view(B, T, E)[:, :L], enc_in2.unflatten(0, (B, L))[:, :, :E])
             ops.copy2d(tfeat, enc_in2[:, E:])
             es2 = self._encoder_fwd(enc_in2, B, L)
-            for l, (_, pre) in enumerate(es2["hw_saved"]):
-                _cap_sel(capture, "recon/hw%d" % l, pre[:, :Din] > 0)
+            if capture is not None:
+                for l, (_, pre) in enumerate(es2["hw_saved"]):
+                    _cap_sel(capture, "recon/hw%d" % l, pre[:, :Din] > 0)
             dmulv2 = _new((B, 2 * Z), dev)
             ops.mahalanobis(mulv, es2["mulv"], cfg.lambda_z, z_loss, dmulv2)
             if train:
@@ -553,31 +633,40 @@ class CGNStep:
         dlogits = logits
         dH1 = _new((NT, Hg), dev)
         ops.gemm(dlogits, P["generator.fc.weight"], dH1)
-        # forked AFTER dH1 (the side stream waits for everything issued so far): dH1 heads the critical path and must
-        # not share the GPU with the equally large dW_fc product; dW_fc then runs beside the latency-bound LSTM steps
-        with self.side(1):
-            ops.gemm(dlogits.t(), h1, G["generator.fc.weight"], N=Hg, K=NT, b_k=h1ax, b_n=LIN)
-            ops.colsum(dlogits, G["generator.fc.bias"])
+        # Parameter gradients of the generator: needed by nothing before its Adam step. With streams overlapped they are
+        # queued (later) and forked behind the encoder's LSTM backward, the step's last persistent launch (see
+        # exclusive()); otherwise they run here.
+        self.begin_defer(capture)
+        self.later(1, lambda: (ops.gemm(dlogits.t(), h1, G["generator.fc.weight"], N=Hg, K=NT, b_k=h1ax, b_n=LIN),
+                               ops.colsum(dlogits, G["generator.fc.bias"])))
         # ---- generator LSTM backward ---------------------------------------------------------------------------
-        dc1 = _new((B, Hg), dev)
-        ops.fill(dc1, 0.0)
-        (dg1,) = engine.lstm_run_bwd([g1], [P["generator.rnn.weight_hh_l1"]], [(dH1, T * Hg, Hg)], [None], [dc1])
-        with self.side(1):
-            engine.lstm_param_grads(g1, dg1, (h0, h0ax), G["generator.rnn.weight_ih_l1"],
-                                    G["generator.rnn.weight_hh_l1"], G["generator.rnn.bias_ih_l1"],
-                                    G["generator.rnn.bias_hh_l1"])
-        dH0 = _new((NT, Hg), dev)
-        ops.gemm(dg1.view(NT, 4 * Hg), P["generator.rnn.weight_ih_l1"], dH0)
-        dc0 = _new((B, Hg), dev)
-        ops.fill(dc0, 0.0)
-        (dg0,) = engine.lstm_run_bwd([g0], [P["generator.rnn.weight_hh_l0"]], [(dH0, T * Hg, Hg)], [None], [dc0])
+        self.exclusive()
+        if fuse2:
+            # one wavefront launch: dg1_t feeds dh0_t = W_ih1^T dg1_t + W_hh0^T dg0_{t+1} inside the kernel
+            dg1, dg0 = _new((B, T, 4 * Hg), dev), _new((B, T, 4 * Hg), dev)
+            ops.lstm2_bwd(P["generator.rnn.weight_hh_l0"], P["generator.rnn.weight_ih_l1"],
+                          P["generator.rnn.weight_hh_l1"], g0.cbuf, g0.gates, g1.cbuf, g1.gates, dH1, T * Hg, Hg,
+                          dg0, dg1, B, T, Hg)
+        else:
+            dc1 = _new((B, Hg), dev)
+            ops.fill(dc1, 0.0)
+            (dg1,) = engine.lstm_run_bwd([g1], [P["generator.rnn.weight_hh_l1"]], [(dH1, T * Hg, Hg)], [None], [dc1])
+            dH0 = _new((NT, Hg), dev)
+            ops.gemm(dg1.view(NT, 4 * Hg), P["generator.rnn.weight_ih_l1"], dH0)
+            dc0 = _new((B, Hg), dev)
+            ops.fill(dc0, 0.0)
+            self.exclusive()
+            (dg0,) = engine.lstm_run_bwd([g0], [P["generator.rnn.weight_hh_l0"]], [(dH0, T * Hg, Hg)], [None], [dc0])
+        self.later(1, lambda: engine.lstm_param_grads(g1, dg1, (h0, h0ax), G["generator.rnn.weight_ih_l1"],
+                                                      G["generator.rnn.weight_hh_l1"], G["generator.rnn.bias_ih_l1"],
+                                                      G["generator.rnn.bias_hh_l1"]))
         dWih0 = G["generator.rnn.weight_ih_l0"]
         dsum = _new((B, 4 * Hg), dev)
         ops.sum_time(dg0, dsum)
-        with self.side(1):
-            engine.lstm_param_grads(g0, dg0, (gen_emb, Axis(E, 0, 0)), dWih0[:, :E], G["generator.rnn.weight_hh_l0"],
-                                    G["generator.rnn.bias_ih_l0"], G["generator.rnn.bias_hh_l0"])
-            ops.gemm(dsum.t(), zc, dWih0[:, E:])
+        self.later(1, lambda: (engine.lstm_param_grads(g0, dg0, (gen_emb, Axis(E, 0, 0)), dWih0[:, :E],
+                                                       G["generator.rnn.weight_hh_l0"], G["generator.rnn.bias_ih_l0"],
+                                                       G["generator.rnn.bias_hh_l0"]),
+                               ops.gemm(dsum.t(), zc, dWih0[:, E:])))
         dzc = _new((B, Z + C), dev)
         ops.gemm(dsum, Wih0[:, E:], dzc)  # g = dzc[:, :Z] = d(79*CE + recon)/dz  (cgn.py:1099, 1142)
         if capture is not None:
@@ -589,8 +678,9 @@ class CGNStep:
                 self.join(1)
                 self._comm([("begin", "gen")])  # travels while the encoder's backward pass runs
         elif not joint:
-            with self.side(1):  # the generator's Adam step follows its gradients; the encoder backward does not wait
-                self._optim_step(opts[1])  # cgn.py:1143
+            # the generator's Adam step follows its gradients (cgn.py:1143); the encoder backward does not wait for it.
+            # dzc above was the last read of a generator weight on the main stream.
+            self.later(1, lambda: self._optim_step(opts[1]))
         # ---- encoder backward (cgn.py:1145-1149): kld_coef*KLD + z_out.backward(g) ---------------------------------
         dmulv = _new((B, 2 * Z), dev)
         ops.reparam_kld_bwd(mulv, eps, dzc, float(kld_coeff) / B, dmulv, dyn=self._dyn(2))
@@ -598,7 +688,8 @@ class CGNStep:
         dtf = _new((N, S), dev)
         ops.copy2d(d_enc_in[:, E:], dtf)
         engine.tdnn_bwd(tsaved, tk, dtf, self._tdnn_kernels(G), G["embedding.char_embed.weight"])
-        self.join(1)
+        self.flush()  # (nothing is left unless the encoder backward ran without parameter gradients)
+        self.join(0, 1)
         if capture is not None:
             capture["enc_grads"] = {n: g.clone() for n, g in self.arenas["enc"].grads.items()}
         if self.dp:

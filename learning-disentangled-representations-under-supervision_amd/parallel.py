@@ -26,12 +26,32 @@ class BucketedAllReduce:
     def _active(self):
         return dist.is_initialized() and (self.force or dist.get_world_size(self.group) > 1)
 
+    def _host_staged(self, flat):
+        """True when the collective moves a device tensor through the host (gloo; rehearsals on one GPU only).
+        ProcessGroupGloo stages HIP tensors on a HIGH-PRIORITY side stream that waits for an event on the caller's
+        stream. On this ROCm stack a high-priority stream that waits behind queued work of a normal-priority stream
+        (a replayed hipGraph segment) stalls that work for seconds to indefinitely - measured without any process group
+        by tools/hp_stream_probe.py (profiles/r02_dp2_hang_probe.txt: 4 ms behind a normal-priority side stream, > 60 s
+        behind a high-priority one). This was round 1's "segmented-graph replay hangs under gloo". RCCL's side stream
+        has normal priority (never request is_high_priority_stream), so the RCCL path has no such wait."""
+        if not flat.is_cuda:
+            return False
+        try:
+            return "gloo" in str(dist.get_backend(self.group)).lower() and "nccl" not in str(
+                dist.get_backend(self.group)).lower()
+        except Exception:  # noqa: BLE001
+            return False
+
     def begin(self, flat):
         """Start the in-place sum of `flat` (1-D fp32 tensor) over all ranks; returns the handles for wait().
         On HIP the collectives run on RCCL's own stream, ordered after everything issued so far on the current
         stream, so kernels launched between begin() and wait() overlap the transfer."""
         if not self._active():
             return []
+        if self._host_staged(flat):
+            # gloo blocks the host in wait() anyway: let the caller's stream drain first, so that gloo's high-priority
+            # stream finds its event already complete and never waits behind queued work (see _host_staged)
+            torch.cuda.current_stream(flat.device).synchronize()
         n = flat.numel()
         handles = []
         for lo in range(0, n, self.bucket_elems):

@@ -85,6 +85,51 @@ def test_lstm_fwd_bwd(dev, B, T, H, Din, bidir, persistent, monkeypatch):
     assert rel(dx.view(B, T, Din), x.grad) < TOL
 
 
+@pytest.mark.parametrize("B,T,H,Din", [(5, 4, 16, 12), (64, 21, 512, 24), (32, 16, 256, 20), (33, 7, 48, 9),
+                                        (64, 1, 512, 8), (20, 3, 128, 16)])
+def test_lstm2_wavefront_fwd_bwd(dev, B, T, H, Din):
+    """The two-layer wavefront launches (cgn_lstm2_fwd/bwd_persistent_f32: layer 1 one timestep behind layer 0, its
+    input projection folded into the recurrence; backward the mirror image) against torch.nn.LSTM(num_layers=2) in
+    fp64: emitted h1, both layers' final states, every parameter gradient and the gradient wrt the input."""
+    engine, ops = _mods()
+    assert ops.lstm2_persistent_bytes(B, T, H, dev) > 0
+    torch.manual_seed(B + T + H)
+    ref = torch.nn.LSTM(Din, H, 2, batch_first=True).double()
+    x = rnd(B, T, Din, seed=1).double().requires_grad_(True)
+    out, (h_n, c_n) = ref(x)
+    w_out = rnd(*out.shape, seed=2).double()
+    (out * w_out).sum().backward()
+    R = dict(ref.named_parameters())
+    P = {n: p.detach().float().to(dev).contiguous() for n, p in R.items()}
+    xd = x.detach().float().to(dev).view(B * T, Din)
+    g0, g1 = engine.LstmSeq(B, T, H, dev, False), engine.LstmSeq(B, T, H, dev, False, need_xg=False)
+    ops.gemm(xd, P["weight_ih_l0"].t(), g0.xg.view(B * T, 4 * H), bias0=P["bias_ih_l0"], bias1=P["bias_hh_l0"])
+    for s_ in (g0, g1):  # poison: the launch itself must write the zero initial state
+        s_.hbuf.fill_(float("nan")), s_.cbuf.fill_(float("nan")), s_.gates.fill_(float("nan"))
+    ops.lstm2_fwd(g0.xg, None, P["weight_hh_l0"], P["weight_ih_l1"], P["weight_hh_l1"], P["bias_ih_l1"],
+                  P["bias_hh_l1"], g0.hbuf, g0.cbuf, g0.gates, g1.hbuf, g1.cbuf, g1.gates, B, T, H)
+    assert ops.lstm_sticky_timeouts() == 0
+    assert rel(g1.hbuf[:, 1:], out) < TOL
+    for l, s_ in enumerate((g0, g1)):
+        assert rel(s_.h_final(), h_n[l]) < TOL and rel(s_.c_final(), c_n[l]) < TOL
+        assert float(s_.hbuf[:, 0].abs().max()) == 0.0 and float(s_.cbuf[:, 0].abs().max()) == 0.0
+    ext = w_out.float().contiguous().to(dev)
+    dg0 = torch.full((B, T, 4 * H), float("nan"), device=dev)
+    dg1 = torch.full((B, T, 4 * H), float("nan"), device=dev)
+    ops.lstm2_bwd(P["weight_hh_l0"], P["weight_ih_l1"], P["weight_hh_l1"], g0.cbuf, g0.gates, g1.cbuf, g1.gates, ext,
+                  T * H, H, dg0, dg1, B, T, H)
+    assert ops.lstm_sticky_timeouts() == 0
+    h0, h0ax = g0.hout_operand()
+    for l, (s_, dg, xop) in enumerate(((g0, dg0, (xd, engine.Axis(Din, 0, 0))), (g1, dg1, (h0, h0ax)))):
+        G = {k: torch.full_like(P[k + "_l%d" % l], float("nan")) for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")}
+        engine.lstm_param_grads(s_, dg, xop, G["weight_ih"], G["weight_hh"], G["bias_ih"], G["bias_hh"])
+        for k, g in G.items():
+            assert rel(g, R[k + "_l%d" % l].grad) < TOL, (k, l)
+    dx = torch.empty(B * T, Din, device=dev)
+    ops.gemm(dg0.view(B * T, 4 * H), P["weight_ih_l0"], dx)
+    assert rel(dx.view(B, T, Din), x.grad) < TOL
+
+
 def test_highway_fwd_bwd(dev):
     engine, ops = _mods()
     N, S = 37, 50

@@ -186,7 +186,6 @@ def test_hip_sampler_matches_the_reference_sampler(dev, graphed, monkeypatch, G)
     if "sampler/params" not in G.files:
         pytest.skip("the reference's sampler failed on this case (a sentence finished: its seed tiling bug)")
     from ldrs_amd.hip import sampler as hs
-    monkeypatch.setattr(hs.BeamSampler, "_cache", {})
     orig_init = hs.BeamSampler.__init__
     monkeypatch.setattr(hs.BeamSampler, "__init__", lambda self, eng, use_graph=True: orig_init(self, eng, graphed))
     model = _model(G)

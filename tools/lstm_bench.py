@@ -1,0 +1,58 @@
+"""Diagnostic: the persistent LSTM launches ALONE on the GPU (cfg2 shapes): us per launch and per timestep."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import ldrs_amd  # noqa
+from ldrs_amd.hip import engine, ops
+
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / reps
+
+
+def seqs(n, B, T, H, revs):
+    out = []
+    for r in revs:
+        s = engine.LstmSeq(B, T, H, dev, r)
+        s.xg.normal_()
+        s.set_initial()
+        out.append(s)
+    return out
+
+
+B, H = 64, 512
+for name, T, revs in (("encoder biLSTM (2 sequences)", 20, (False, True)), ("one generator layer", 21, (False,))):
+    ss = seqs(len(revs), B, T, H, revs)
+    W = [torch.randn(4 * H, H, device=dev) / H ** 0.5 for _ in revs]
+    us = timeit(lambda: engine.lstm_run_fwd(ss, W))
+    print("%-32s fwd  %7.1f us  %5.2f us/step" % (name, us, us / T))
+    dh = torch.randn(B, T, H, device=dev)
+    dcs = [torch.zeros(B, H, device=dev) for _ in revs]
+    us = timeit(lambda: engine.lstm_run_bwd(ss, W, [(dh, T * H, H)] * len(revs), [None] * len(revs), dcs))
+    print("%-32s bwd  %7.1f us  %5.2f us/step" % (name, us, us / T))
+T = 21
+g0, g1 = seqs(2, B, T, H, (False, False))
+Ws = [torch.randn(4 * H, H, device=dev) / H ** 0.5 for _ in range(3)]
+bs = [torch.randn(4 * H, device=dev) * 0.1 for _ in range(2)]
+us = timeit(lambda: ops.lstm2_fwd(g0.xg, None, Ws[0], Ws[1], Ws[2], bs[0], bs[1], g0.hbuf, g0.cbuf, g0.gates, g1.hbuf,
+                                  g1.cbuf, g1.gates, B, T, H))
+print("%-32s fwd  %7.1f us  %5.2f us/step" % ("generator, 2 layers fused", us, us / T))
+dh = torch.randn(B, T, H, device=dev)
+dg0, dg1 = torch.empty(B, T, 4 * H, device=dev), torch.empty(B, T, 4 * H, device=dev)
+us = timeit(lambda: ops.lstm2_bwd(Ws[0], Ws[1], Ws[2], g0.cbuf, g0.gates, g1.cbuf, g1.gates, dh, T * H, H, dg0, dg1, B, T, H))
+print("%-32s bwd  %7.1f us  %5.2f us/step" % ("generator, 2 layers fused", us, us / T))
+print("sticky timeouts:", ops.lstm_sticky_timeouts())
