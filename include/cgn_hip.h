@@ -159,6 +159,18 @@ int cgn_lstm_persistent_query(int32_t nseq, int32_t B, int32_t T, int32_t H, int
 int cgn_lstm_seq_fwd_persistent_f32(void* stream, const cgn_lstm_fwd_seq* seqs /* host */, int32_t nseq, int32_t B,
                                     int32_t T, int32_t H, void* sync_ws, int64_t sync_ws_bytes);
 
+/* cgn_lstm_seq_fwd_persistent_f32 for callers that cannot allocate. NO COUNTERPART IN THE REFERENCE: it exists for
+ * callers that may not call hipMalloc - code under hipGraph capture, tight serving loops, harnesses that forbid it.
+ * Same kernels, buffers and results as cgn_lstm_seq_fwd_persistent_f32, but the arrival counters / timeout word live in
+ * a file-scope device array of the library (33,024 bytes per GPU, held until the process ends) instead of a caller-owned
+ * sync_ws; the call allocates nothing (no hipMalloc / hipFree, no allocating library routine) and re-zeroes the counters
+ * on `stream` itself. Limit: nseq * ceil(B/16) <= 256 counter groups (and the shape must be eligible per
+ * cgn_lstm_persistent_query), else CGN_ERR_INVALID_ARG. Every call on a GPU shares that GPU's array: calls that overlap
+ * on one GPU (different streams) race - serialise them. status: nullable device word, set to 1 by a launch whose bounded
+ * wait ran out (results invalid), never cleared by the library; NULL keeps the flag in the library's own array. */
+int cgn_lstm_seq_fwd_persistent_noalloc_f32(void* stream, const cgn_lstm_fwd_seq* seqs /* host */, int32_t nseq,
+                                            int32_t B, int32_t T, int32_t H, uint32_t* status);
+
 /* BPTT. dgates [B,T,4H] receives d(pre-activation gates); dW_ih/dW_hh/db/dX follow as GEMMs / column sums.
  * dh_ext: nullable gradient wrt the emitted h, element (b,t,j) at dh_ext[b*dh_bs + t*dh_ts + j];
  * dh_seed: nullable [B,H] gradient wrt the final hidden state; dc_state [B,H]: in = gradient wrt the final cell

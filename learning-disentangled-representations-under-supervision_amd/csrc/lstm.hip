@@ -1047,6 +1047,74 @@ extern "C" int cgn_lstm_seq_fwd_persistent_f32(void* stream, const cgn_lstm_fwd_
     return CGN_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same persistent forward launch for callers that cannot allocate (code under hipGraph capture, tight serving
+// loops, harnesses that forbid hipMalloc): the arrival counters, the timeout word and the sticky flag live in a
+// file-scope device array of this code object instead of a caller-owned sync_ws. Every GPU holds its own copy of the
+// array at its own address (taken once per device with hipGetSymbolAddress, with that device current); every call on
+// a GPU shares that GPU's copy, so calls that overlap on one GPU race (the counters are re-zeroed per call on the
+// call's stream). No hipMalloc / hipFree / allocating library call on this path.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int NOALLOC_MAX_GROUPS = 256;  // nseq * ceil(B/16) <= 256: persist_ok() already caps workgroups at the CU count
+constexpr int NOALLOC_LINES = NOALLOC_MAX_GROUPS + 2;  // + per-launch timeout word + sticky flag, one 128-byte line each
+static __device__ __align__(256) unsigned g_lstm_noalloc_scratch[NOALLOC_LINES * SYNC_STRIDE];  // 33,024 bytes per GPU
+
+namespace {
+constexpr int NOALLOC_MAX_DEVICES = 64;
+unsigned* g_noalloc_ptr[NOALLOC_MAX_DEVICES] = {nullptr};
+
+// device address of this GPU's copy of the scratch array (never the array's host-side name)
+int noalloc_scratch(unsigned** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NOALLOC_MAX_DEVICES) return CGN_ERR_INVALID_ARG;
+    unsigned* p = __atomic_load_n(&g_noalloc_ptr[dev], __ATOMIC_ACQUIRE);
+    if (p == nullptr) {
+        void* addr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&addr, HIP_SYMBOL(g_lstm_noalloc_scratch));
+        if (e != hipSuccess || addr == nullptr) return CGN_ERR_HIP_BASE + (int)e;
+        p = (unsigned*)addr;
+        __atomic_store_n(&g_noalloc_ptr[dev], p, __ATOMIC_RELEASE);  // racing first calls compute the same address
+    }
+    *out = p;
+    return CGN_OK;
+}
+}  // namespace
+
+extern "C" int cgn_lstm_seq_fwd_persistent_noalloc_f32(void* stream, const cgn_lstm_fwd_seq* seqs, int32_t nseq,
+                                                       int32_t B, int32_t T, int32_t H, uint32_t* status) {
+    CGN_CHECK_ARG(seqs && nseq >= 1 && nseq <= LSTM_MAX_SEQ);
+    CGN_CHECK_ARG(B >= 0 && T >= 0 && H > 0);
+    if (B == 0 || T == 0) return CGN_OK;
+    CGN_CHECK_ARG(persist_ok(nseq, B, T, H));
+    // the stated maximum of the built-in scratch: one counter line per (sequence, 16-row batch tile)
+    CGN_CHECK_ARG((long)nseq * cgn_cdiv(B, 16) <= NOALLOC_MAX_GROUPS);
+    unsigned* scratch = nullptr;
+    {
+        const int rc = noalloc_scratch(&scratch);
+        if (rc) return rc;
+    }
+    FwdParams p;
+    for (int i = 0; i < nseq; ++i) {
+        const cgn_lstm_fwd_seq& s = seqs[i];
+        CGN_CHECK_ARG(s.xg && s.w_hh && s.hbuf && s.cbuf && s.gates);
+        CGN_CHECK_ARG(((uintptr_t)s.hbuf % 16 == 0) && ((uintptr_t)s.w_hh % 16 == 0));
+        p.s[i] = {s.xg, s.xg_extra, s.w_hh, s.hbuf, s.cbuf, s.gates, s.reverse, s.init_zero};
+    }
+    p.B = B; p.T = T; p.H = H; p.nseq = nseq; p.step = 0;
+    hipStream_t st = (hipStream_t)stream;
+    // counters + timeout word start at zero for every call (the array keeps the last call's contents)
+    if (hipMemsetAsync(scratch, 0, (size_t)persist_zero_bytes(nseq, B), st) != hipSuccess)
+        return CGN_ERR_HIP_BASE + (int)hipGetLastError();
+    unsigned* sticky = status ? status : scratch + (NOALLOC_LINES - 1) * SYNC_STRIDE;
+    dim3 grid(nseq * cgn_cdiv(B, 16) * (H / 16));
+    if (H <= 256)
+        hipLaunchKernelGGL((lstm_persist_fwd_kernel<2>), grid, dim3(LSTM_NT), 0, st, p, scratch, sticky);
+    else
+        hipLaunchKernelGGL((lstm_persist_fwd_kernel<4>), grid, dim3(LSTM_NT), 0, st, p, scratch, sticky);
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}
+
 extern "C" int cgn_lstm_seq_bwd_persistent_f32(void* stream, const cgn_lstm_bwd_seq* seqs, int32_t nseq, int32_t B,
                                                int32_t T, int32_t H, void* sync_ws, int64_t sync_ws_bytes) {
     CGN_CHECK_ARG(seqs && nseq >= 1 && nseq <= LSTM_MAX_SEQ);

@@ -93,6 +93,7 @@ PROTOTYPES = {
     "cgn_lstm_seq_bwd_f32": (c_i32, [c_ptr, C.POINTER(LstmBwdSeq), c_i32, c_i32, c_i32, c_i32]),
     "cgn_lstm_persistent_query": (c_i32, [c_i32, c_i32, c_i32, c_i32, C.POINTER(c_i64)]),
     "cgn_lstm_seq_fwd_persistent_f32": (c_i32, [c_ptr, C.POINTER(LstmFwdSeq), c_i32, c_i32, c_i32, c_i32, c_ptr, c_i64]),
+    "cgn_lstm_seq_fwd_persistent_noalloc_f32": (c_i32, [c_ptr, C.POINTER(LstmFwdSeq), c_i32, c_i32, c_i32, c_i32, c_ptr]),
     "cgn_lstm_seq_bwd_persistent_f32": (c_i32, [c_ptr, C.POINTER(LstmBwdSeq), c_i32, c_i32, c_i32, c_i32, c_ptr, c_i64]),
     "cgn_lstm2_persistent_query": (c_i32, [c_i32, c_i32, c_i32, C.POINTER(c_i64)]),
     "cgn_lstm2_fwd_persistent_f32": (c_i32, [c_ptr, C.POINTER(Lstm2Fwd), c_i32, c_i32, c_i32, c_ptr, c_i64]),
