@@ -10,9 +10,11 @@ as train_functions.py:90 passes) + the three Adam updates. The beam sampler is e
 synthetic. Workload = BASELINE.json configs[1]: vocab 20k, seq len 20, batch 64/GPU, emb 300,
 hidden 512, z 64, fp32. Inputs are resident in HBM before the timed region.
 
-Prints ONE JSON line (rank 0) with the throughput, a `roofline` object for the dominant kernel (the NT 128x128 fp32
-MFMA GEMM; per-launch times from HIP events on the launch stream inside the timed region) and, at N=1, a
-`cpu_baseline` object (the CPU oracle restatement of the same step on the host cores, bounded sample).
+Prints ONE JSON line (rank 0) with the throughput, a `roofline` object for the dominant kernel — the GEMM kernel SYMBOL
+with the most time in the step, found live: every product of the step is timed with HIP events recorded directly around
+its MFMA kernel on the stream it is launched on (cgn_gemm_timed_f32), aggregated per symbol — a `step_mfma` object (all
+MFMA FLOPs of the step / step time / peak), and, at N=1, a `cpu_baseline` object (the CPU oracle restatement of the same
+step on the host cores, bounded sample). --gemm-table PATH writes the per-shape table of the step's products.
 """
 import argparse
 import json
@@ -64,8 +66,10 @@ def cpu_baseline(cfgd, host_data, global_step, budget_s=25.0):
     data = {k: v for k, v in host_data.items() if not k.startswith("mask_")}
     masks = dict(labelled=host_data["mask_labelled"], generated=host_data["mask_generated"])
     B = data["enc_word"].shape[0]
+    n_warm = 3  # allocator, thread pool, first-touch of the 20k x 512 weight pages
     t0 = time.perf_counter()
-    O.wake_sleep_step(model, opts, data, global_step, calc_z_loss=False, masks=masks)  # warm-up (allocator, threads)
+    for _ in range(n_warm):
+        O.wake_sleep_step(model, opts, data, global_step, calc_z_loss=False, masks=masks)
     warm = time.perf_counter() - t0
     times = []
     while len(times) < 10 and (sum(times) + warm) < budget_s:
@@ -73,12 +77,34 @@ def cpu_baseline(cfgd, host_data, global_step, budget_s=25.0):
         O.wake_sleep_step(model, opts, data, global_step, calc_z_loss=False, masks=masks)
         times.append(time.perf_counter() - t0)
     if not times:
-        times = [warm]
+        times = [warm / n_warm]
     times.sort()
     med = times[len(times) // 2]
     return {"value": B / med, "unit": "sentences/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d full wake-sleep steps of the same cfg2 batch (B=%d) after 1 warm-up, median; CPU fp32 "
-                      "torch restatement oracle/cgn_oracle.py" % (len(times), B)}
+            "cpu_model": host_cpu_model(),
+            "sample": "%d full wake-sleep steps of the same cfg2 batch (B=%d) after %d warm-up steps, median; CPU fp32 "
+                      "torch restatement oracle/cgn_oracle.py, %d torch threads" % (len(times), B, n_warm,
+                                                                                  torch.get_num_threads())}
+
+
+def host_cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def gemm_symbol(sym):
+    """Kernel symbol of a product from ops.GEMM_PROFILE's key (csrc/gemm_core.h gemm_kernel's template arguments)."""
+    bt, a_kc, b_kc, vec, exp, smb, bf16 = sym
+    b = lambda v: "true" if v else "false"  # noqa: E731
+    kstep = (16 if bt == 128 else 32) * (2 if bf16 else 1)
+    return "cgn_gemm::gemm_kernel<%d, %s, %s, %d, %s, 2, %d, %s, %s>" % (bt, b(a_kc), b(b_kc), vec, b(exp), kstep, b(smb),
+                                                                       b(bf16))
 
 
 def main():
@@ -94,6 +120,8 @@ def main():
     ap.add_argument("--compute", choices=("f32", "bf16"), default="f32",
                     help="MFMA operand type: f32 = the metric's parity mode; bf16 = north-star's optional mode (operands "
                          "rounded to bf16 inside the GEMM kernels, fp32 accumulate/storage; tests/test_step_gpu.py bf16 case)")
+    ap.add_argument("--gemm-table", metavar="PATH", help="write the per-shape table of the step's products (shape, tile, "
+                    "split, us, TFLOP/s, fraction of peak; live HIP-event timings) to PATH")
     ap.add_argument("--force-dp", action="store_true",
                     help="single-GPU rehearsal of the data-parallel schedule: a one-rank RCCL group, collectives issued")
     args = ap.parse_args()
@@ -160,7 +188,7 @@ def main():
             step()
         barrier()
         if profile_inside:
-            ops.GEMM_PROFILE = {"variant": (128, 1, 1), "records": []}
+            ops.GEMM_PROFILE = {"variant": None, "records": []}
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = step()
@@ -172,38 +200,63 @@ def main():
             el = tt.item()
         return el, out
 
-    def summarise(eg_losses, prof):
-        """Host-side copies of everything emit() needs from the device (the watchdog path must not touch the GPU)."""
+    def summarise(eg_losses, prof, passes):
+        """Host-side copies of everything emit() needs from the device (the watchdog path must not touch the GPU).
+        prof: ops.GEMM_PROFILE after `passes` instrumented steps - one record per product launch, HIP events directly
+        around its MFMA kernel. Aggregated per kernel symbol and per (symbol, split, shape)."""
         ce = eg_losses[0].item()
         if not (ce == ce) or ce <= 0:
             raise SystemExit("non-finite loss in the benchmark step")
-        # the roofline kernel is ONE symbol: the linear-epilogue NT 128-tile variant = the vocabulary projection (the
-        # dlogits product shares the tile shape but runs the softmax-backward epilogue variant, a different symbol)
-        recs = [r for r in prof["records"] if r[0] == (128, 1, 1)]
-        flops = sum(2.0 * M * N * K for _, _, M, N, K, _, _ in recs)
-        ms = sum(e0.elapsed_time(e1) for *_, e0, e1 in recs)
-        return flops, ms, len(recs)
+        by_sym, by_shape = {}, {}
+        for sym, sk, M, N, K, e0, e1 in prof["records"]:
+            ms = e0.elapsed_time(e1)
+            fl = 2.0 * M * N * K
+            a = by_sym.setdefault(sym, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += ms; a[2] += fl
+            a = by_shape.setdefault((sym, sk, M, N, K), [0, 0.0])
+            a[0] += 1; a[1] += ms
+        lstm_flops = 0.0
+        He, Hg = cfgd["encoder_rnn_size"], cfgd["decoder_rnn_size"]
+        mm = lambda H: 2.0 * BATCH * 4 * H * H  # noqa: E731 - one [B,H] x [H,4H] product of a recurrence step
+        lstm_flops += 2 * SEQ * 2 * mm(He)                              # encoder: 2 directions x (fwd h.W_hh, bwd dg.W_hh)
+        fused = 3 if ops.LSTM_FUSE_LAYERS else 2                        # fused launches also carry layer 1's W_ih products
+        lstm_flops += (SEQ + 1) * 2 * fused * mm(Hg)                    # generator: 2 layers, forward and backward
+        return dict(by_sym=by_sym, by_shape=by_shape, passes=passes, group_flops=prof.get("group_flops", 0.0) / passes,
+                    lstm_flops=lstm_flops)
 
-    def emit(elapsed, summary, launch, graph_timing):
+    def emit(elapsed, summary, launch, graph_timing, extra=None):
         """rank 0: the ONE JSON line of the contract, for a timed region of exactly K steps that took `elapsed`."""
-        flops, ms, launches = summary
-        # HBM bytes per launch of the roofline kernel: PMC counters cannot be read from inside the run, so the figure
-        # comes from the committed rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py; FETCH_SIZE and
-        # WRITE_SIZE in separate runs, FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes)
+        passes = summary["passes"]
+        peak = FP32_MFMA_PEAK_TFLOPS if args.compute == "f32" else BF16_MFMA_PEAK_TFLOPS
+        # the roofline kernel = the symbol the step spends the most time in
+        sym, (launches, ms, flops) = max(summary["by_sym"].items(), key=lambda kv: kv[1][1])
+        name = gemm_symbol(sym)
+        # HBM bytes per launch of that symbol: PMC counters cannot be read from inside the run, so the figure comes from
+        # the committed rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py; FETCH_SIZE and WRITE_SIZE in
+        # separate runs, corrected for gfx950 as MI355X_MICROARCH.md prescribes), averaged over the symbol's launches
         traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        tp = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if os.path.exists(tp) and args.workload == "cfg2" and args.compute == "f32":
             with open(tp) as f:
                 tj = json.load(f)
+            tot_b = tot_n = 0
             for k, v in tj["kernels"].items():
-                if k.startswith("gemm_kernel<128, true, true, 3, false, 2, 16, false, false>") and k.endswith("g1727"):
-                    traffic, traffic_src = v["traffic"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, %d launches)" % v["launches"]
+                if k.startswith(name.replace("cgn_gemm::", "") + " ") or k.startswith(name.replace("cgn_gemm::", "") + "("):
+                    tot_b += v["traffic"] * v["launches"]
+                    tot_n += v["launches"]
+            if tot_n:
+                traffic = tot_b / tot_n
+                traffic_src = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc, %d launches of this symbol)" % tot_n
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        peak = FP32_MFMA_PEAK_TFLOPS if args.compute == "f32" else BF16_MFMA_PEAK_TFLOPS
+        ms_step = 1e3 * elapsed / args.steps
+        gemm_flops = sum(v[2] for v in summary["by_sym"].values()) / passes
+        step_flops = gemm_flops + summary["group_flops"] + summary["lstm_flops"]
+        shapes = sorted(((M, N, K, sk, cnt / passes, 1e3 * t / cnt) for (sy, sk, M, N, K), (cnt, t) in
+                         summary["by_shape"].items() if sy == sym), key=lambda r: -r[4] * r[5])
         out = {
             "metric": "wake-sleep training sentences/sec", "value": world * BATCH * args.steps / elapsed,
             "unit": "sentences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.compute, "data": "synthetic",
             "config": {"workload": "CGN full wake-sleep training step (disc step + c inference + enc/gen step + 3 Adam), "
                                    + ("BASELINE configs[1]: vocab 20k, seq len 20, batch 64/GPU, emb 300, hidden 512, "
@@ -218,19 +271,54 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
-                         "kernel": ("cgn_gemm::gemm_kernel<128,true,true,3,false,2,16,false,false> (NT fp32 MFMA GEMM, 128x128 tile, "
-                                    if args.compute == "f32" else
-                                    "cgn_gemm::gemm_kernel<128,true,true,3,false,2,32,false,true> (NT bf16-operand MFMA GEMM, 128x128 "
-                                    "tile, ") + "linear epilogue: the vocabulary projection h1 @ fc.weight^T + bias -> logits)",
-                         "launches_per_step": 1.0,
+                         "kernel": name + " (the GEMM kernel symbol with the most time in the step: %.0f us of %.0f us "
+                                          "per step)" % (1e3 * ms / passes, 1e3 * ms_step),
+                         "launches_per_step": launches / passes,
                          "avg_launch_us": 1e3 * ms / max(launches, 1),
                          "algorithmic_gflop_per_launch": flops / max(launches, 1) / 1e9,
-                         "timing": "HIP events around each launch, " + ("instrumented eager pass after the timed "
-                                   "graph replays" if graph_timing else "inside the timed region")},
+                         "shapes": [{"M": M, "N": N, "K": K, "splitk": sk, "per_step": n, "us": round(us, 1),
+                                     "tflops": round(2.0 * M * N * K / us / 1e6, 1)} for M, N, K, sk, n, us in shapes[:6]],
+                         "timing": "HIP events directly around each launch of the symbol on its launch stream, "
+                                   + ("instrumented eager pass after the timed graph replays" if graph_timing else
+                                      "inside the timed region")},
+            # all MFMA work of one step (every GEMM product + the grouped convolution products + the LSTM recurrences)
+            # against the step time: the fraction of the fp32 MFMA peak the WHOLE step sustains
+            "step_mfma": {"gflop_per_step": step_flops / 1e9, "gemm_gflop": gemm_flops / 1e9,
+                          "grouped_gflop": summary["group_flops"] / 1e9, "lstm_gflop": summary["lstm_flops"] / 1e9,
+                          "achieved_tflops": step_flops / (ms_step * 1e-3) / 1e12,
+                          "utilisation": step_flops / (ms_step * 1e-3) / 1e12 / peak,
+                          "gemm_kernel_ms_per_step": sum(v[1] for v in summary["by_sym"].values()) / passes},
         }
+        if extra:
+            out.update(extra)
+        if args.gemm_table and rank == 0:
+            write_gemm_table(args.gemm_table, summary, peak, ms_step)
         if world == 1 and not args.no_cpu_baseline and not dp:
             out["cpu_baseline"] = cpu_baseline(cfgd, host_data, global_step)
         print(json.dumps(out), flush=True)
+
+    def write_gemm_table(path, summary, peak, ms_step):
+        passes = summary["passes"]
+        rows = sorted(summary["by_shape"].items(), key=lambda kv: -kv[1][1])
+        with open(path, "w") as f:
+            f.write("# per-shape table of the step's GEMM products (%s, %s): HIP events directly around each MFMA kernel\n"
+                    "# launch (split-K reduce launches excluded), %d instrumented steps; step time %.3f ms\n" %
+                    (args.workload, args.compute, passes, ms_step))
+            f.write("%-62s %2s %6s %6s %6s %5s %8s %8s %6s\n" % ("kernel symbol", "sk", "M", "N", "K", "n/st", "us", "TFLOP/s",
+                                                               "frac"))
+            tot = 0.0
+            for (sym, sk, M, N, K), (cnt, t) in rows:
+                us = 1e3 * t / cnt
+                tf = 2.0 * M * N * K / us / 1e6
+                tot += t / passes
+                f.write("%-62s %2d %6d %6d %6d %5.1f %8.1f %8.1f %6.3f\n" % (gemm_symbol(sym).replace("cgn_gemm::", ""), sk, M,
+                                                                            N, K, cnt / passes, us, tf, tf / peak))
+            f.write("# per symbol\n")
+            for sym, (cnt, t, fl) in sorted(summary["by_sym"].items(), key=lambda kv: -kv[1][1]):
+                f.write("%-62s launches/step %5.1f  us/step %8.1f  TFLOP/s %7.1f  frac %5.3f\n" %
+                        (gemm_symbol(sym).replace("cgn_gemm::", ""), cnt / passes, 1e3 * t / passes, fl / t / 1e9,
+                         fl / t / 1e9 / peak))
+            f.write("# all products: %.1f us per step\n" % (1e3 * tot))
 
     def check_lstm():
         """The persistent LSTM launches need their workgroups resident together; a bounded wait that runs out leaves a
@@ -260,7 +348,7 @@ def main():
         eager_result = timed(eager_step, True)
         eager_prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
         torch.cuda.synchronize()
-        eager_summary = summarise(eager_result[1][2], eager_prof)
+        eager_summary = summarise(eager_result[1][2], eager_prof, args.steps)
         # A persistent LSTM launch that timed out on ANY rank (its workgroups could not become resident together, e.g.
         # beside a collective's kernels) invalidates the run: all ranks switch to the per-timestep kernels and repeat.
         bad = torch.tensor([float(ops.lstm_sticky_timeouts()) +
@@ -283,18 +371,21 @@ def main():
             eager_result = timed(eager_step, True)
             eager_prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
             torch.cuda.synchronize()
-            eager_summary = summarise(eager_result[1][2], eager_prof)
+            eager_summary = summarise(eager_result[1][2], eager_prof, args.steps)
         if not replicas_identical():
             raise SystemExit("data-parallel replicas diverged in the eager schedule")
         check_lstm()
         limit = float(os.environ.get("CGN_DP_GRAPH_TIMEOUT", "120"))
 
         def bail():
+            # The replay did not come back. The eager measurement is still a valid one and is printed, but marked, and
+            # the process exits NON-ZERO: a hung replay must never be recorded as a clean run.
             if rank == 0:
                 emit(eager_result[0], eager_summary,
-                     "eager (the segmented-graph replay did not finish within %.0f s)" % limit + lstm_note, False)
+                     "eager (the segmented-graph replay did not finish within %.0f s)" % limit + lstm_note, False,
+                     extra={"replay_hung": True})
             sys.stdout.flush()
-            os._exit(0)
+            os._exit(3)
 
         import threading
         watchdog = threading.Timer(limit, bail)
@@ -302,6 +393,7 @@ def main():
         watchdog.start()
 
     use_graph = want_graph
+    prof_passes = args.steps
     if use_graph:
         from ldrs_amd.hip.graph import GraphedWakeSleep
         try:
@@ -327,12 +419,14 @@ def main():
         # an instrumented eager pass of the SAME step on the same data right after the timed region (its kernels run
         # alone on the stream, as they do inside the graph's forward chain); rocprofv3's kernel trace of this command
         # (profiles/) shows the in-graph durations.
-        ops.GEMM_PROFILE = {"variant": (128, 1, 1), "records": []}
-        for _ in range(max(3, min(args.steps, 10))):
+        ops.GEMM_PROFILE = {"variant": None, "records": []}
+        prof_passes = max(3, min(args.steps, 10))
+        for _ in range(prof_passes):
             eager_step()
         torch.cuda.synchronize()
     elif eager_result is not None:
         (elapsed, losses), ops.GEMM_PROFILE = eager_result, eager_prof
+        prof_passes = args.steps
     else:
         elapsed, losses = timed(eager_step, True)
     if watchdog is not None:
@@ -349,11 +443,11 @@ def main():
                   (rank, "a timed-out LSTM launch" if bad.item() > 0 else "diverged replicas"), file=sys.stderr, flush=True)
             ops.clear_lstm_sticky_timeouts()
             (elapsed, losses), ops.GEMM_PROFILE = eager_result, eager_prof
-            use_graph = False
+            use_graph, prof_passes = False, args.steps
     if use_graph and eager_result is not None and eager_result[0] < elapsed:
         # both were measured over exactly K steps: report the faster schedule, and say which one it is
         (elapsed, losses), ops.GEMM_PROFILE = eager_result, eager_prof
-        use_graph = False
+        use_graph, prof_passes = False, args.steps
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
     torch.cuda.synchronize()
     check_lstm()
@@ -362,7 +456,7 @@ def main():
                   ("eager" if eager_result is None or not want_graph else
                    "eager (faster here than the segmented-graph replay, which also ran)"))
         torch.cuda.synchronize()
-        emit(elapsed, summarise(losses[2], prof), launch + lstm_note, use_graph)
+        emit(elapsed, summarise(losses[2], prof, prof_passes), launch + lstm_note, use_graph)
     if world > 1:
         torch.distributed.barrier()
     if torch.distributed.is_initialized():

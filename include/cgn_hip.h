@@ -108,6 +108,12 @@ int cgn_gemm_group_f32(void* stream, const cgn_gemm_desc* descs /* host array */
  * orientations); used by bench.py to attribute per-launch timings to kernel symbols. Launches nothing. */
 int cgn_gemm_plan(const cgn_gemm_desc* desc /* host */, int32_t* tile, int32_t* splitk, int32_t* a_kcontig,
                   int32_t* b_kcontig);
+/* cgn_gemm_f32 with two hipEvent_t recorded on `stream` directly before and directly after the product's MFMA kernel
+ * (the split-K reduce launch, if any, follows ev_stop): bench.py's live per-kernel timing, so that the event time is the
+ * duration of the one kernel symbol rocprofv3 reports. vec_mode: nullable, receives the kernel's vector-load template
+ * argument (bit 0: A loads 16 bytes, bit 1: B). Measurement aid, no counterpart in the reference. */
+int cgn_gemm_timed_f32(void* stream, const cgn_gemm_desc* desc /* host */, void* ev_start, void* ev_stop,
+                       int32_t* vec_mode);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Temperature softmax + NLL  (model/cgn.py:1086-1092: logits/tau -> F.log_softmax -> F.nll_loss, mean over ALL rows)

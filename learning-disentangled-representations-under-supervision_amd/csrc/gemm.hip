@@ -166,7 +166,8 @@ static int prepare_gemm(const cgn_gemm_desc* d, GemmParams& p, bool& a_kc, bool&
     return CGN_OK;
 }
 
-extern "C" int cgn_gemm_f32(void* stream, const cgn_gemm_desc* d) {
+static int run_gemm(void* stream, const cgn_gemm_desc* d, hipEvent_t ev_start, hipEvent_t ev_stop,
+                    int32_t* vec_mode = nullptr) {
     GemmParams p;
     bool a_kc = false, b_kc = false;
     {
@@ -188,11 +189,14 @@ extern "C" int cgn_gemm_f32(void* stream, const cgn_gemm_desc* d) {
 
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)tiles, (unsigned)splitk);
+    if (vec_mode) *vec_mode = (p.a_vec ? 1 : 0) | (p.b_vec ? 2 : 0);
+    if (ev_start && hipEventRecord(ev_start, s) != hipSuccess) return CGN_ERR_HIP_BASE + (int)hipGetLastError();
     if (d->compute == CGN_COMPUTE_BF16)
         launch_gemm_bf16ops(p, bt, a_kc, b_kc, grid, s);
     else
         launch_gemm_f32ops(p, bt, a_kc, b_kc, grid, s);
     CGN_LAUNCH_CHECK();
+    if (ev_stop && hipEventRecord(ev_stop, s) != hipSuccess) return CGN_ERR_HIP_BASE + (int)hipGetLastError();
     if (splitk > 1) {
         int blocks = cgn_cdiv((long)d->M * p.ldw / 4, 256);
         if (blocks > 2048) blocks = 2048;
@@ -201,6 +205,14 @@ extern "C" int cgn_gemm_f32(void* stream, const cgn_gemm_desc* d) {
         CGN_LAUNCH_CHECK();
     }
     return CGN_OK;
+}
+
+extern "C" int cgn_gemm_f32(void* stream, const cgn_gemm_desc* d) { return run_gemm(stream, d, nullptr, nullptr); }
+
+extern "C" int cgn_gemm_timed_f32(void* stream, const cgn_gemm_desc* d, void* ev_start, void* ev_stop,
+                                  int32_t* vec_mode) {
+    CGN_CHECK_ARG(ev_start && ev_stop);
+    return run_gemm(stream, d, (hipEvent_t)ev_start, (hipEvent_t)ev_stop, vec_mode);
 }
 
 extern "C" int cgn_gemm_group_f32(void* stream, const cgn_gemm_desc* descs, int32_t n) {

@@ -83,6 +83,7 @@ ACT_TANH = 1
 PROTOTYPES = {
     "cgn_abi_version": (c_i32, []),
     "cgn_gemm_f32": (c_i32, [c_ptr, C.POINTER(GemmDesc)]),
+    "cgn_gemm_timed_f32": (c_i32, [c_ptr, C.POINTER(GemmDesc), c_ptr, c_ptr, C.POINTER(c_i32)]),
     "cgn_gemm_group_f32": (c_i32, [c_ptr, C.POINTER(GemmDesc), c_i32]),
     "cgn_act_maxpool_group_f32": (c_i32, [c_ptr, c_i32, C.POINTER(c_ptr), C.POINTER(c_i32), C.POINTER(c_i32),
                                           C.POINTER(c_i32), c_i32, c_i32, c_ptr, c_i64, c_ptr, c_i64]),

@@ -196,12 +196,17 @@ def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, 
         _lib.check(lib.cgn_gemm_plan(C.byref(d), C.byref(t_), C.byref(s_), C.byref(ak), C.byref(bk)), "cgn_gemm_plan")
         key = (t_.value, ak.value, bk.value)
         if prof["variant"] is None or prof["variant"] == key:
+            # events directly around the MFMA kernel (cgn_gemm_timed_f32), on the stream it is launched on
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             with torch.cuda.device(dev):
-                e0.record()
-                _lib.check(lib.cgn_gemm_f32(_stream(), C.byref(d)), "cgn_gemm_f32")
-                e1.record()
-            prof["records"].append((key + (("smb",) if softmax_bwd is not None else ()), s_.value, M, N, K, e0, e1))
+                e0.record(), e1.record()  # torch creates the hipEvent_t lazily, at the first record
+                vec = C.c_int32()
+                _lib.check(lib.cgn_gemm_timed_f32(_stream(), C.byref(d), e0.cuda_event, e1.cuda_event, C.byref(vec)),
+                           "cgn_gemm_timed_f32")
+            # (tile, A k-contiguous, B k-contiguous, vector mode, exp A-loader, softmax-bwd epilogue, bf16 operands)
+            sym = key + (vec.value, d.a_transform == _lib.ATRANS_EXP, softmax_bwd is not None,
+                         d.compute == _lib.COMPUTE_BF16)
+            prof["records"].append((sym, s_.value, M, N, K, e0, e1))
             return out
     with torch.cuda.device(dev):
         _lib.check(lib.cgn_gemm_f32(_stream(), C.byref(d)), "cgn_gemm_f32")
@@ -226,6 +231,9 @@ def gemm_group(calls):
         if out.device != dev:
             raise ValueError("grouped products must live on one device")
         arr[i] = gemm(a, b, out, _desc_only=True, **kw)
+    if GEMM_PROFILE is not None:  # bench.py's step-level MFMA accounting (FLOPs only; grouped launches are not timed)
+        GEMM_PROFILE["group_flops"] = GEMM_PROFILE.get("group_flops", 0.0) + sum(
+            2.0 * arr[i].M * arr[i].N * arr[i].K for i in range(n))
     with torch.cuda.device(dev):
         _lib.check(lib.cgn_gemm_group_f32(_stream(), arr, n), "cgn_gemm_group_f32")
 

@@ -143,3 +143,85 @@ def test_checkpoint_round_trip_through_state_dict(dev):
         dl, c, eg = e2.wake_sleep(o2, data, 0.5, 0.9)
         losses.append([float(x) for x in dl] + [float(x) for x in eg[:4]])
     assert losses[0] == losses[1]
+
+
+def test_timed_out_persistent_launch_stops_the_training_loop(dev, tmp_path):
+    """A persistent LSTM launch whose bounded wait ran out leaves a sticky device word (include/cgn_hip.h); the product
+    path must not train on, log or checkpoint what came after it. The word is forced here (a healthy GPU never sets it)
+    and every host sync point of the loop is expected to raise: the logging points, the checkpoint, the end of the
+    loop, the sampler."""
+    import ldrs_amd  # noqa: F401
+    from ldrs_amd import train_functions
+    from ldrs_amd.hip import ops
+    from ldrs_amd.utils.synthetic import SyntheticDataHandler
+    cfg, ocfg, oracle, model, _ = _build(dev)
+    handler = SyntheticDataHandler(cfg, 20, cfg.max_seq_len - 1, num_batches=3)
+    train_functions.train_complete_model(model, handler, cfg, True, 0.3, None, None, "t", num_steps=1)  # creates the scratch
+    assert ops.lstm_sticky_timeouts() == 0 and len(ops._lstm_sync) > 0
+    try:
+        for ws in ops._lstm_sync.values():
+            ws[-32] = 1  # what a timed-out launch writes (persist_sync_bytes(): the last 128-byte line)
+        assert ops.lstm_sticky_timeouts() > 0
+        with pytest.raises(ops.LstmTimeoutError):
+            ops.raise_on_lstm_timeout()
+        with pytest.raises(ops.LstmTimeoutError):  # quiet loop: the check at the end of the loop
+            train_functions.train_complete_model(model, handler, cfg, True, 0.3, None, None, "t", num_steps=2)
+        with pytest.raises(ops.LstmTimeoutError):  # logging loop: the first emit()
+            train_functions.train_complete_model(model, handler, cfg, True, 0.3, None, None, "t", num_steps=2,
+                                                 log_every=1, validate=False)
+        with pytest.raises(ops.LstmTimeoutError):  # the sampler's own sync point
+            train_functions.generate_samples_for_disc_training(model, handler, cfg, True, 4, 4)
+        train_functions.CHECKPOINT_EVERY, keep = 1, train_functions.CHECKPOINT_EVERY
+        try:
+            with pytest.raises(ops.LstmTimeoutError):  # never write weights trained on a timed-out launch
+                train_functions.train_complete_model(model, handler, cfg, True, 0.3, None, str(tmp_path), "t", num_steps=1)
+            assert not list(tmp_path.iterdir())
+        finally:
+            train_functions.CHECKPOINT_EVERY = keep
+    finally:
+        ops.clear_lstm_sticky_timeouts()
+    assert ops.lstm_sticky_timeouts() == 0
+    train_functions.train_complete_model(model, handler, cfg, True, 0.3, None, None, "t", num_steps=1)
+
+
+class _Writer:
+    def __init__(self):
+        self.rows = []
+
+    def add_scalar(self, tag, value, step):
+        self.rows.append((tag, float(value), step))
+
+
+def test_validation_loops_follow_the_reference_schedule(dev, monkeypatch):
+    """train_functions.py:152-263: the two validation loops, run by train_complete_model on the reference's schedule
+    (discriminator every 40th, encoder/generator every 100th iteration, both at iteration 0) and stand-alone; forward
+    only: no parameter moves, the model is back in training mode afterwards, the logged names are the reference's."""
+    import ldrs_amd  # noqa: F401
+    from ldrs_amd import train_functions
+    from ldrs_amd.utils.synthetic import SyntheticDataHandler
+    cfg, ocfg, oracle, model, _ = _build(dev)
+    handler = SyntheticDataHandler(cfg, 10, cfg.max_seq_len - 1, num_batches=3, val_lines=20, num_dev_batches=2)
+    monkeypatch.setattr(train_functions, "ENC_GEN_VALID_BATCH", 10)  # the reference's 500 (:165) needs 500 validation lines
+    model.discriminator_mode(train_mode=True), model.encoder_mode(train_mode=True), model.generator_mode(train_mode=True)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    w = _Writer()
+    out = train_functions.enc_gen_validation(model, handler, True, 7, model.valid_encoder_generator(), w, batch_size=10,
+                                             verbose=False)
+    assert set(out) == {"encoder_loss", "generator_loss", "generator_z_loss", "generator_c_loss", "cross_entropy", "kld",
+                        "kld_coef", "temp_coef"}
+    assert all(v == v for v in out.values()) and out["cross_entropy"] > 0 and out["kld"] >= 0
+    out_d = train_functions.disc_validation(model, handler, cfg, True, 7, handler.num_dev_sentiment_batches,
+                                            model.discriminator_sentiment_valid(handler, True, return_accuracy=True), 10,
+                                            w, verbose=False)
+    assert set(out_d) == {"labeled_cross_entropy", "labeled_accuracy", "generated_cross_entropy", "generated_accuracy"}
+    assert 0.0 <= out_d["labeled_accuracy"] <= 100.0 and 0.0 <= out_d["generated_accuracy"] <= 100.0
+    assert all(torch.equal(p.detach(), before[n]) for n, p in model.named_parameters()), "validation moved a parameter"
+    assert {t.split("/")[0] for t, _, _ in w.rows} == {"valid_enc_gen", "valid_discriminator"}
+    # inside the loop: iteration 0 runs both validations, iteration 1 neither; training still moves the weights
+    w2 = _Writer()
+    train_functions.train_complete_model(model, handler, cfg, True, 0.3, w2, None, "t", num_steps=2)
+    tags = [(t, s) for t, _, s in w2.rows]
+    assert ("valid_discriminator/labeled_accuracy", 0) in tags and ("valid_enc_gen/cross_entropy", 0) in tags
+    assert not any(t.startswith("valid_") and s == 1 for t, s in tags)
+    assert ("train_discriminator/total_loss", 0) in tags and ("train_enc_gen/encoder_loss", 0) in tags
+    assert any(not torch.equal(p.detach(), before[n]) for n, p in model.named_parameters())
