@@ -39,6 +39,12 @@ CFGS = {
     "cfg2": dict(max_word_len=12, max_seq_len=21, word_vocab_size=20000, char_vocab_size=64, word_embed_size=300,
                  encoder_rnn_size=512, latent_variable_size=64, decoder_rnn_size=512, decoder_num_layers=2,
                  sentiment_kernel_size=(3, 4, 5), sentiment_kernel_num=100),
+    # BASELINE.json configs[3] (large-vocab stress): vocab 50k, seq len 40, hidden 1024, z 64 at FULL model size. The
+    # oracle case runs it at a reduced batch (8 sentences: every kernel sees the full V / H / L extents, the fp64 oracle
+    # step stays at seconds); the full batch of 256 is covered by test_cfg4_full_batch_properties below
+    "cfg4": dict(max_word_len=12, max_seq_len=41, word_vocab_size=50000, char_vocab_size=64, word_embed_size=300,
+                 encoder_rnn_size=1024, latent_variable_size=64, decoder_rnn_size=1024, decoder_num_layers=2,
+                 sentiment_kernel_size=(3, 4, 5), sentiment_kernel_num=100),
     # multi-attribute extension (two discriminators, c = [sentiment, tense], filter widths 1..5), small
     "multi": dict(max_word_len=8, max_seq_len=9, word_vocab_size=203, char_vocab_size=31, word_embed_size=32,
                   kernels=((1, 5), (2, 7), (3, 6)), encoder_rnn_size=32, latent_variable_size=12, decoder_rnn_size=48,
@@ -116,7 +122,7 @@ def build(name, dev, seed=0):
 
 @pytest.mark.parametrize("name,B,calc_z", [("tiny", 4, False), ("tiny", 5, True), ("odd", 7, True), ("mid", 16, False),
                                            ("mid", 8, True), ("cfg1", 32, False), ("cfg2", 64, False), ("multi", 6, True), ("multi", 9, False),
-                                           ("cfg5", 64, False)])
+                                           ("cfg5", 64, False), ("cfg4", 8, False)])
 def test_wake_sleep_step_matches_oracle(dev, name, B, calc_z):
     _step_parity(dev, name, B, calc_z, TOL)
 
@@ -273,3 +279,63 @@ def test_validation_closure_is_forward_only(dev):
                                calc_z_loss=True, eps_recon=data["eps_recon"].double())
     for i in (0, 1, 2, 3, 6, 7):
         assert rel(out[i], ref[i]) < TOL, i
+
+
+def _grads_of_one_step(model, cfg, data, masks, rows, gstep, dev):
+    """Gradients (before Adam) and losses of one wake-sleep step on the given batch rows, through the closures."""
+    B = len(rows)
+    sub = {k: v[rows] for k, v in data.items()}
+    HANDLER.cfg, HANDLER.d = cfg, sub
+    disc_train = model.discriminator_sentiment_trainer(HANDLER, True)
+    enc_gen_train = model.train_encoder_generator()
+    cap = {}
+    model.prep_disc_training()
+    d = disc_train(sub["x_generated"].tolist(), sub["c_generated"].float().view(B, -1), 0,
+                   mask_labelled=masks["labelled"][rows].to(dev), mask_generated=masks["generated"][rows].to(dev), capture=cap)
+    batch = [sub["enc_word"].numpy(), sub["enc_char"].numpy(), sub["dec_word"].numpy(), None, sub["target"].numpy()]
+    model.discriminator_mode(train_mode=False)
+    c = model.discriminator_forward(batch, B, True, uniform=sub["c_uniform"])
+    model.prep_enc_gen_training()
+    eg = enc_gen_train(batch, B, True, masks["gen_drop"][rows].to(dev), c, gstep, calc_z_loss=False, eps=sub["eps"],
+                       capture=cap)
+    grads = {}
+    for key in ("disc_grads", "gen_grads", "enc_grads"):
+        grads.update({n: g.detach().double().cpu() for n, g in cap[key].items()})
+    losses = [float(x) for x in d] + [float(x) for x in eg[:4]]
+    return grads, losses, c.cpu()
+
+
+def test_cfg4_full_batch_properties(dev):
+    """BASELINE.json configs[3] at FULL size (vocab 50k, seq len 40, hidden 1024, batch 256), where the fp64 oracle would
+    need minutes: size-independent properties instead. Every loss of the step is a MEAN over the batch, so the
+    gradients of the full batch are the average of the gradients of its two halves - computed by differently shaped
+    launches of every kernel (other tile counts, split-K plans, batch tiles of the recurrences) from identical weights.
+    Bars: 1e-4 on every gradient tensor and loss (fp32 summation order only); the inferred codes c are identical."""
+    from ldrs_amd.hip import ops
+    ocfg, oracle, cfg, model = build("cfg4", dev)
+    del oracle
+    B, L = 256, ocfg.max_seq_len - 1
+    F_ = len(ocfg.sentiment_kernel_size) * ocfg.sentiment_kernel_num
+    data = O.synthetic_batch(ocfg, B, L, seed=321)
+    g = torch.Generator().manual_seed(11)
+    masks = dict(labelled=(torch.rand(B, F_, generator=g) < 0.7).float() / 0.7,
+                 generated=(torch.rand(B, F_, generator=g) < 0.7).float() / 0.7,
+                 gen_drop=(torch.rand(B, L + 1, ocfg.word_embed_size, generator=g) < 0.7).float() / 0.7)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    rows = torch.arange(B)
+    full, l_full, c_full = _grads_of_one_step(model, cfg, data, masks, rows, 5000, dev)
+    halves = []
+    for part in (rows[:B // 2], rows[B // 2:]):
+        model.load_state_dict(sd)  # the step above moved the weights
+        halves.append(_grads_of_one_step(model, cfg, data, masks, part, 5000, dev))
+    assert torch.equal(c_full, torch.cat([halves[0][2], halves[1][2]]))
+    assert all(v == v and abs(v) < 1e6 for v in l_full), l_full
+    for a, b0, b1 in zip(l_full, halves[0][1], halves[1][1]):
+        assert abs(a - 0.5 * (b0 + b1)) <= 1e-4 * max(1.0, abs(a)), (a, b0, b1)
+    worst = ("", 0.0)
+    for n, gf in full.items():
+        e = rel(0.5 * (halves[0][0][n] + halves[1][0][n]), gf)
+        worst = max(worst, (n, e), key=lambda t: t[1])
+        assert e < 1e-4, (n, e)
+    assert ops.lstm_sticky_timeouts() == 0
+    print("cfg4 full batch: worst half/half vs full gradient error %.2e (%s)" % (worst[1], worst[0]))
