@@ -365,7 +365,9 @@ class CGNStep:
             ops.gemm(hw_out, P["encoder.rnn.weight_ih_l0" + sfx].t(), s.xg.view(N, 4 * He),
                      bias0=P["encoder.rnn.bias_ih_l0" + sfx], bias1=P["encoder.rnn.bias_hh_l0" + sfx])
             s.set_initial()
-        self.exclusive()
+        # No exclusive() here: the only work that can still be running is the tail of the discriminator step / c inference
+        # on side stream 0, a chain of kernels with 1-113 workgroups that fit beside the recurrence's 256 (measured: the
+        # join cost 54 us per step, the chain's last ~80 us ran with the whole GPU waiting; beside the launch it is free).
         engine.lstm_run_fwd([sf, sr], [P["encoder.rnn.weight_hh_l0"], P["encoder.rnn.weight_hh_l0_reverse"]])
         ctx = _new((B, 2 * He), self.dev)
         ops.copy2d(sf.c_final(), ctx[:, :He])
