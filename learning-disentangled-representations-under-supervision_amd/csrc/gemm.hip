@@ -159,6 +159,24 @@ static int prepare_gemm(const cgn_gemm_desc* d, GemmParams& p, bool& a_kc, bool&
               (a_kc ? axis_vec_ok(d->a_k, d->a_m, d->K) : axis_vec_ok(d->a_m, d->a_k, d->M));
     p.b_vec = ((uintptr_t)d->B % 16 == 0) &&
               (b_kc ? axis_vec_ok(d->b_k, d->b_n, d->K) : axis_vec_ok(d->b_n, d->b_k, d->N));
+    // fast K addressing: plain K axes, 16-byte loads on both operands, both operands inside 2 GB. An operand's bound is
+    // its last addressed element rounded up to the quad that a 16-byte load may touch (the vector-load conditions above
+    // already promise that this quad is memory the caller owns).
+    p.fastk = 0; p.a_bytes = 0; p.b_bytes = 0;
+    if (p.a_vec && p.b_vec && d->a_k.rpg == 0 && d->b_k.rpg == 0 && d->K > 0) {
+        auto last = [](const cgn_axis& ax, long n) {
+            const long i = n - 1;
+            return ax.rpg > 0 ? (i / ax.rpg) * ax.gs + (i % ax.rpg) * ax.stride : i * ax.stride;
+        };
+        const long ea = (last(d->a_m, d->M) + last(d->a_k, d->K) + 4) / 4 * 4;
+        const long eb = (last(d->b_k, d->K) + last(d->b_n, d->N) + 4) / 4 * 4;
+        const long lim = (1L << 31) / 4 - 64;
+        if (ea < lim && eb < lim && d->a_k.stride < (1 << 24) && d->b_k.stride < (1 << 24)) {
+            p.fastk = 1;
+            p.a_bytes = (unsigned)(ea * 4);
+            p.b_bytes = (unsigned)(eb * 4);
+        }
+    }
     CGN_CHECK_ARG((uintptr_t)d->workspace % 16 == 0);
     p.ws = d->workspace;
     p.dyn = d->dyn_scalars;
@@ -189,7 +207,7 @@ static int run_gemm(void* stream, const cgn_gemm_desc* d, hipEvent_t ev_start, h
 
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)tiles, (unsigned)splitk);
-    if (vec_mode) *vec_mode = (p.a_vec ? 1 : 0) | (p.b_vec ? 2 : 0);
+    if (vec_mode) *vec_mode = (p.a_vec ? 1 : 0) | (p.b_vec ? 2 : 0) | (p.fastk ? 4 : 0);
     if (ev_start && hipEventRecord(ev_start, s) != hipSuccess) return CGN_ERR_HIP_BASE + (int)hipGetLastError();
     if (d->compute == CGN_COMPUTE_BF16)
         launch_gemm_bf16ops(p, bt, a_kc, b_kc, grid, s);

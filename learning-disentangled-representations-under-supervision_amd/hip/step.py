@@ -94,6 +94,7 @@ class CGNStep:
         # graph can be replayed while the schedules (utils/functional.py:28-42) advance.
         self.dynamic = False
         self.dyn = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._zero1 = torch.zeros(1, dtype=torch.float32, device=dev)  # read-only
         # one text-CNN per attribute of c (the reference: one, `sentiment_discriminator`; BASELINE configs[4]: two)
         self.disc_prefixes = ["sentiment_discriminator."] + ["attribute_discriminators.%d." % i
                                                              for i in range(len(model.attribute_discriminators))]
@@ -565,9 +566,9 @@ class CGNStep:
         tgt = target.reshape(-1)
         lse, nll, ce = ops.softmax_nll_fwd(logits, tgt, inv_tau, dyn=self._dyn())
         need_soft = use_disc or calc_z_loss
-        c_loss, z_loss = _new((1,), dev), _new((1,), dev)
-        ops.fill(c_loss, 0.0)
-        ops.fill(z_loss, 0.0)
+        # (a loss that this step does not compute reads as the engine's constant zero: no fill kernel on the critical path)
+        c_loss = self._zero1
+        z_loss = _new((1,), dev) if calc_z_loss else self._zero1
         if need_soft:
             # ---- soft embedding (cgn.py:1103-1108): softmax(logits/tau) @ E, probabilities formed in the A loader
             out_emb = _new((NT, E), dev)
