@@ -633,14 +633,14 @@ struct GemmGroup {
     int n;
 };
 
-template <int BT, bool A_KC, bool B_KC, int VEC, int S, int BK = (BT == 128 ? 16 : 32), bool BF = false>
+template <int BT, bool A_KC, bool B_KC, int VEC, int S, int BK = (BT == 128 ? 16 : 32), bool BF = false, bool FK = false>
 __global__ __launch_bounds__(NT, 2) void gemm_group_kernel(const GemmGroup g) {
     int j = 0;
     while (j + 1 < g.n && (int)blockIdx.x >= g.tile_end[j]) ++j;  // block-uniform
     const int local = blockIdx.x - (j ? g.tile_end[j - 1] : 0);  // (split, tile) of member j, tile fastest
     const int ntiles = g.p[j].tiles_m * g.p[j].tiles_n;
     const int split = local / ntiles;
-    gemm_tile<BT, A_KC, B_KC, VEC, false, S, BK, false, BF>(g.p[j], split, local - split * ntiles);
+    gemm_tile<BT, A_KC, B_KC, VEC, false, S, BK, false, BF, FK>(g.p[j], split, local - split * ntiles);
 }
 
 // Sums the split-K slabs in fixed order z = 0..splitk-1 (bitwise reproducible). Slab rows are ldw = ceil4(N) floats
@@ -751,17 +751,30 @@ void launch_gemm(const GemmParams& p, int bt, bool a_kc, bool b_kc, dim3 grid, h
     }
 }
 
-template <int VEC, bool BF>
-void launch_group_v(const GemmGroup& g, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s) {
+template <int VEC, bool BF, bool FK>
+void launch_group_vk(const GemmGroup& g, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s) {
     constexpr int BK = bk_of<64, BF>();
     if (a_kc && b_kc)
-        hipLaunchKernelGGL((gemm_group_kernel<64, true, true, VEC, 2, BK, BF>), dim3(blocks), dim3(NT), 0, s, g);
+        hipLaunchKernelGGL((gemm_group_kernel<64, true, true, VEC, 2, BK, BF, FK>), dim3(blocks), dim3(NT), 0, s, g);
     else if (a_kc && !b_kc)
-        hipLaunchKernelGGL((gemm_group_kernel<64, true, false, VEC, 2, BK, BF>), dim3(blocks), dim3(NT), 0, s, g);
+        hipLaunchKernelGGL((gemm_group_kernel<64, true, false, VEC, 2, BK, BF, FK>), dim3(blocks), dim3(NT), 0, s, g);
     else if (!a_kc && b_kc)
-        hipLaunchKernelGGL((gemm_group_kernel<64, false, true, VEC, 2, BK, BF>), dim3(blocks), dim3(NT), 0, s, g);
+        hipLaunchKernelGGL((gemm_group_kernel<64, false, true, VEC, 2, BK, BF, FK>), dim3(blocks), dim3(NT), 0, s, g);
     else
-        hipLaunchKernelGGL((gemm_group_kernel<64, false, false, VEC, 2, BK, BF>), dim3(blocks), dim3(NT), 0, s, g);
+        hipLaunchKernelGGL((gemm_group_kernel<64, false, false, VEC, 2, BK, BF, FK>), dim3(blocks), dim3(NT), 0, s, g);
+}
+
+template <int VEC, bool BF>
+void launch_group_v(const GemmGroup& g, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s) {
+    if constexpr (VEC == 3) {
+        bool fk = true;  // fast K addressing only if every member qualifies (one kernel variant per group)
+        for (int i = 0; i < g.n; ++i) fk = fk && g.p[i].fastk;
+        if (fk) {
+            launch_group_vk<VEC, BF, true>(g, a_kc, b_kc, blocks, s);
+            return;
+        }
+    }
+    launch_group_vk<VEC, BF, false>(g, a_kc, b_kc, blocks, s);
 }
 
 template <bool BF>

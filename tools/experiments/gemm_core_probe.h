@@ -14,10 +14,6 @@
 //     (bitwise reproducible, no float atomics);
 //   * blockIdx -> tile mapping is XCD-aware: blocks that share an XCD (blockIdx % 8) walk neighbouring tiles.
 #pragma once
-#ifndef FASTK
-#define FASTK 0
-#endif
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #include <type_traits>
 
 #include "../../learning-disentangled-representations-under-supervision_amd/csrc/common.h"
@@ -77,6 +73,10 @@ struct GemmParams {
     int tiles_m, tiles_n;
     int order;  // 0: remap over (split, tile), shorter tile axis fastest; 1: same remap, m fastest; 2: remap over tiles only
     float alpha, beta, a_scale, ep_inv_tau, ep_ce_scale;
+    // fast K addressing (template flag FK): both K axes are plain and both operands span < 2^31 bytes, so a lane's byte
+    // offset is fixed for the whole K loop and the K position is a scalar (buffer loads: voffset + soffset)
+    int fastk;
+    unsigned a_bytes, b_bytes;  // bounds of the two buffer resources (loads beyond return 0)
 };
 
 constexpr int g_unroll_mult = 2;
@@ -99,6 +99,7 @@ __device__ __forceinline__ float apply_epilogue(const GemmParams& p, int row, in
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -124,8 +125,9 @@ __device__ __forceinline__ u32x2 pack_bf16x4(const f32x4& v) {
 //   KC = true : memory is contiguous along k (row-major [rows][k]): thread = (row, k-quad), one float4 load per chunk
 //   KC = false: memory is contiguous along the row index ([k][rows]): thread = one row, lanes run along rows, scalar
 //               loads (a wave covers 64 consecutive rows = 256 contiguous bytes per k), 4 k per chunk
-template <int ROWS, bool KC, int BK, int S, bool VEC, bool EXP, bool BF>
+template <int ROWS, bool KC, int BK, int S, bool VEC, bool EXP, bool BF, bool FK = false>
 struct TileLoader {
+    static_assert(!FK || VEC, "fast K addressing is built for the 16-byte load paths");
     // LDS row stride in 4-byte words: BK + 4 floats, or (BF) BK + 8 bf16: 16 bytes of padding either way
     static constexpr int LDK = BF ? (BK + 8) / 2 : BK + 4;
     static constexpr int QUADS = ROWS * BK / 4;  // 4-k chunks per tile
@@ -144,6 +146,10 @@ struct TileLoader {
     static_assert(KC || !VEC || ((KP == 2 || KP == 4) && KP == PER), "row-vector loader geometry");
 
     f32x4 regs[S][PER];  // S register stages: S tiles of global loads in flight per thread
+    // FK: buffer resource of the operand, the lane's fixed byte offsets and the byte stride of one k
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff[FK ? (KC ? PER : KP) : 1];
+    int kbytes;
     long roff[KC ? PER : 1];
     bool rok[KC ? PER : 1];
     bool rok4[4];
@@ -185,26 +191,44 @@ struct TileLoader {
     // serialises the L2 round trips; measured: 1.25 us per K step for a lone block.)
     //   VEC: one 16-byte load per chunk. A quad may straddle kend only at the end of the contiguous axis, where the
     //        host has checked that the padded row stride covers it; quads wholly beyond kend re-read the quad at kbeg.
+    // FK only, after init(): the operand's buffer resource and this lane's byte offsets at k = 0
+    __device__ __forceinline__ void init_fast(const float* base, unsigned bytes, const Axis& ak) {
+        const int tid = threadIdx.x;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+        kbytes = (int)ak.stride * 4;
+        if constexpr (KC) {
+            constexpr int QPR = BK / 4;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) voff[i] = ((int)roff[i] + (tid % QPR) * 4) * 4;
+        } else {
+#pragma unroll
+            for (int j = 0; j < KP; ++j) voff[j] = (int)roff[0] * 4 + ((tid / RQ) * KP + j) * kbytes;
+        }
+    }
+
     __device__ __forceinline__ void load(int st, const float* __restrict__ base, const Axis& ak, int k0, int kbeg,
                                          int kend) {
         const int tid = threadIdx.x;
+        if constexpr (FK) {
+            // No address arithmetic in the K loop (the generic path below spends ~45 VALU instructions per K step on
+            // 64-bit offset math, clustered between the MFMAs: 10-17 % of the kernel, tools/experiments/gemm_loop_probe).
+            // Nothing is clamped: a load beyond the operand returns 0 (buffer bounds), one beyond kend but inside it reads
+            // values that store<true>() masks (tiles that are stored unmasked lie wholly inside the K range).
+            const int soff = __builtin_amdgcn_readfirstlane(k0) * kbytes;
+            constexpr int NL = KC ? PER : KP;
+#pragma unroll
+            for (int i = 0; i < NL; ++i)
+                regs[st][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[i], soff, 0));
+            return;
+        }
         if constexpr (KC) {
             constexpr int QPR = BK / 4;
             const int q = tid % QPR;
             const int k = k0 + q * 4;
             if constexpr (VEC) {
-#if FASTK
-                // plain k axis (stride 1): per-lane byte offset fixed for the whole K loop, the K position is a scalar
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
-                const int kk = __builtin_amdgcn_readfirstlane(k0 < kend ? k0 : kbeg);
-#pragma unroll
-                for (int i = 0; i < PER; ++i)
-                    regs[st][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((int)roff[i] + q * 4) * 4, kk * 4, 0));
-#else
                 const long koff = axis_off(ak, k < kend ? k : kbeg);
 #pragma unroll
                 for (int i = 0; i < PER; ++i) regs[st][i] = *reinterpret_cast<const f32x4*>(base + roff[i] + koff);
-#endif
             } else {
                 long koff[4];
 #pragma unroll
@@ -338,7 +362,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // VEC: bit 0 = operand A is read with 16-byte loads, bit 1 = operand B (each along its own contiguous axis)
 // SMB: the batched softmax-backward epilogue is compiled in (only the dlogits product's variant: inside the shared
 // variant its registers cost the vocabulary projection 10 %).
-template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK, bool SMB = false, bool BF = false>
+template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK, bool SMB = false, bool BF = false,
+          bool FK = false>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, const int t) {
     constexpr int TW = BT / 64;  // 32x32 accumulators per wave along each dim
     constexpr int LDK = BF ? (BK + 8) / 2 : BK + 4;  // LDS row stride (4-byte words) of both operand images
@@ -364,10 +389,15 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
     const int wm = wave >> 1, wn = wave & 1;
     const float a_scale = (EXP && p.dyn) ? p.dyn[0] : p.a_scale;
 
-    TileLoader<BT, A_KC, BK, S, (VEC & 1) != 0, EXP, BF> la;
-    TileLoader<BT, B_KC, BK, S, (VEC & 2) != 0, false, BF> lb;
+    static_assert(!FK || VEC == 3, "fast K addressing needs 16-byte loads on both operands");
+    TileLoader<BT, A_KC, BK, S, (VEC & 1) != 0, EXP, BF, FK> la;
+    TileLoader<BT, B_KC, BK, S, (VEC & 2) != 0, false, BF, FK> lb;
     la.init(p.am, m0, p.M, p.a_row_param);
     lb.init(p.bn, n0, p.N, nullptr);
+    if constexpr (FK) {
+        la.init_fast(p.A, p.a_bytes, p.ak);
+        lb.init_fast(p.B, p.b_bytes, p.bk);
+    }
 
     // the 64-tile has one 32x32 output per wave: two accumulator chains (even / odd k) halve the dependent-MFMA chain
     constexpr int NC = (TW == 1) ? 2 : 1;
@@ -467,9 +497,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb) {
             if (jb + 1 < NBLK) {
-#if ABLATE < 4
                 read_frags(As, Bs, jb + 1, (jb + 1) & 1);
-#endif
                 __builtin_amdgcn_sched_barrier(0);  // issued BEFORE this block's MFMAs, which then cover the round trip
             }
             if (jb == 0) {
@@ -486,12 +514,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
                 // pin the order: this block's MFMAs stay BELOW the barrier and the reads behind it (left alone, the
                 // scheduler hoists the MFMAs above the barrier and the wave meets the LDS round trip with an empty pipe)
                 __builtin_amdgcn_sched_barrier(0);
-#if ABLATE < 3
                 __syncthreads();
-#endif
-#if ABLATE < 4
                 read_frags(An, An + TILE, 0, 0);  // block 0 of the next tile: lands under this block's MFMAs
-#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             mfma_block(jb & 1);
@@ -581,8 +605,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
 }
 
 template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK = (BT == 128 ? 16 : 32), bool SMB = false,
-          bool BF = false>
-__global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
+          bool BF = false, bool FK = false>
+__global__ __launch_bounds__(NT, PLB) void gemm_kernel(const GemmParams p) {
     // Work item = (K split, tile). Default (order 2): the XCD remap runs over the tile list, m fastest (neighbouring
     // tiles share the B, usually the weight, panel). Orders 0/1 remap over the whole (split, tile) list so that an XCD
     // owns whole K ranges of a split-K product: that cuts the memory-side fetch of the three tall-K products (PMC:
@@ -599,7 +623,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
         split = w / ntiles;
         t = w - split * ntiles;
     }
-    gemm_tile<BT, A_KC, B_KC, VEC, EXP, S, BK, SMB, BF>(p, split, t);
+    gemm_tile<BT, A_KC, B_KC, VEC, EXP, S, BK, SMB, BF, FK>(p, split, t);
 }
 
 // Grouped launch: up to GROUP_MAX independent products (same kernel variant) in ONE launch; block b works on the
@@ -669,31 +693,42 @@ constexpr int bk_of() {
     return BF ? (BT == 128 ? 32 : 64) : (BT == 128 ? 16 : 32);
 }
 
-template <int BT, int VEC, bool EXP, bool BF>
-void launch_v(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
+template <int BT, int VEC, bool EXP, bool BF, bool FK>
+void launch_vk(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
     constexpr int S = 2;  // register stages (1, 3, 4 were swept in round 1: 2 is best or equal on every step shape)
     constexpr int BK = bk_of<BT, BF>();
     if constexpr (EXP) {  // the exp transform needs a k-contiguous A (checked by the caller)
         if (b_kc)
-            hipLaunchKernelGGL((gemm_kernel<BT, true, true, VEC, true, S, BK, false, BF>), grid, dim3(NT), 0, s, p);
+            hipLaunchKernelGGL((gemm_kernel<BT, true, true, VEC, true, S, BK, false, BF, FK>), grid, dim3(NT), 0, s, p);
         else
-            hipLaunchKernelGGL((gemm_kernel<BT, true, false, VEC, true, S, BK, false, BF>), grid, dim3(NT), 0, s, p);
+            hipLaunchKernelGGL((gemm_kernel<BT, true, false, VEC, true, S, BK, false, BF, FK>), grid, dim3(NT), 0, s, p);
     } else {
         if constexpr (BT == 128 && VEC == 3) {
             if (a_kc && b_kc && p.epilogue == CGN_EPI_SOFTMAX_BWD && p.splitk == 1) {
-                hipLaunchKernelGGL((gemm_kernel<BT, true, true, VEC, false, S, BK, true, BF>), grid, dim3(NT), 0, s, p);
+                hipLaunchKernelGGL((gemm_kernel<BT, true, true, VEC, false, S, BK, true, BF, FK>), grid, dim3(NT), 0, s, p);
                 return;
             }
         }
         if (a_kc && b_kc)
-            hipLaunchKernelGGL((gemm_kernel<BT, true, true, VEC, false, S, BK, false, BF>), grid, dim3(NT), 0, s, p);
+            hipLaunchKernelGGL((gemm_kernel<BT, true, true, VEC, false, S, BK, false, BF, FK>), grid, dim3(NT), 0, s, p);
         else if (a_kc && !b_kc)
-            hipLaunchKernelGGL((gemm_kernel<BT, true, false, VEC, false, S, BK, false, BF>), grid, dim3(NT), 0, s, p);
+            hipLaunchKernelGGL((gemm_kernel<BT, true, false, VEC, false, S, BK, false, BF, FK>), grid, dim3(NT), 0, s, p);
         else if (!a_kc && b_kc)
-            hipLaunchKernelGGL((gemm_kernel<BT, false, true, VEC, false, S, BK, false, BF>), grid, dim3(NT), 0, s, p);
+            hipLaunchKernelGGL((gemm_kernel<BT, false, true, VEC, false, S, BK, false, BF, FK>), grid, dim3(NT), 0, s, p);
         else
-            hipLaunchKernelGGL((gemm_kernel<BT, false, false, VEC, false, S, BK, false, BF>), grid, dim3(NT), 0, s, p);
+            hipLaunchKernelGGL((gemm_kernel<BT, false, false, VEC, false, S, BK, false, BF, FK>), grid, dim3(NT), 0, s, p);
     }
+}
+
+template <int BT, int VEC, bool EXP, bool BF>
+void launch_v(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
+    if constexpr (VEC == 3) {
+        if (p.fastk) {
+            launch_vk<BT, VEC, EXP, BF, true>(p, a_kc, b_kc, grid, s);
+            return;
+        }
+    }
+    launch_vk<BT, VEC, EXP, BF, false>(p, a_kc, b_kc, grid, s);
 }
 
 template <int BT, bool EXP, bool BF>

@@ -7,6 +7,15 @@
 #ifndef PTILE
 #define PTILE 128
 #endif
+#ifndef PLB
+#define PLB 2
+#endif
+#ifndef PSTAGES
+#define PSTAGES 2
+#endif
+#ifndef PBK128
+#define PBK128 16
+#endif
 #include "gemm_core_probe.h"
 #include <cstdio>
 #include <cstdlib>
@@ -28,14 +37,15 @@ int main(int argc, char** argv) {
     p.am = make_axis(am); p.ak = make_axis(ak); p.bk = make_axis(bk); p.bn = make_axis(bn);
     p.M = M; p.N = N; p.K = K; p.k_per_split = (K + KROUND - 1) / KROUND * KROUND; p.splitk = 1;
     p.a_vec = 1; p.b_vec = 1; p.a_transform = CGN_ATRANS_NONE; p.epilogue = CGN_EPI_LINEAR;
+    p.fastk = 1; p.a_bytes = (unsigned)((size_t)M * K * 4); p.b_bytes = (unsigned)((size_t)N * K * 4);
     p.tiles_m = (M + PTILE - 1) / PTILE; p.tiles_n = (N + PTILE - 1) / PTILE; p.order = 2; p.alpha = 1.f;
     dim3 grid(p.tiles_m * p.tiles_n, 1);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
-        for (int w = 0; w < 10; ++w) hipLaunchKernelGGL((gemm_kernel<PTILE, true, true, 3, false, 2>), grid, dim3(NT), 0, 0, p);
+        for (int w = 0; w < 10; ++w) hipLaunchKernelGGL((gemm_kernel<PTILE, true, true, 3, false, PSTAGES, (PTILE == 128 ? PBK128 : 32), false, false, true>), grid, dim3(NT), 0, 0, p);
         hipEventRecord(e0);
-        for (int w = 0; w < 10; ++w) hipLaunchKernelGGL((gemm_kernel<PTILE, true, true, 3, false, 2>), grid, dim3(NT), 0, 0, p);
+        for (int w = 0; w < 10; ++w) hipLaunchKernelGGL((gemm_kernel<PTILE, true, true, 3, false, PSTAGES, (PTILE == 128 ? PBK128 : 32), false, false, true>), grid, dim3(NT), 0, 0, p);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms / 10 < best) best = ms / 10;
