@@ -103,9 +103,9 @@ def gemm_symbol(sym):
     bt, a_kc, b_kc, vec, exp, smb, bf16 = sym
     b = lambda v: "true" if v else "false"  # noqa: E731
     kstep = (16 if bt == 128 else 32) * (2 if bf16 else 1)
-    # vec: bits 0/1 = 16-byte loads on A/B (the template's VEC), bit 2 = fast K addressing (the template's FK)
-    return "cgn_gemm::gemm_kernel<%d, %s, %s, %d, %s, 2, %d, %s, %s, %s>" % (bt, b(a_kc), b(b_kc), vec & 3, b(exp), kstep,
-                                                                           b(smb), b(bf16), b(vec & 4))
+    # vec: bits 0/1 = 16-byte loads on A/B (the template's VEC), bits 2.. = fast K addressing mode (the template's FK)
+    return "cgn_gemm::gemm_kernel<%d, %s, %s, %d, %s, 2, %d, %s, %s, %d>" % (bt, b(a_kc), b(b_kc), vec & 3, b(exp), kstep,
+                                                                           b(smb), b(bf16), vec >> 2)
 
 
 def main():

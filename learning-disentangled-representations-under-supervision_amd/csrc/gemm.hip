@@ -163,7 +163,12 @@ static int prepare_gemm(const cgn_gemm_desc* d, GemmParams& p, bool& a_kc, bool&
     // its last addressed element rounded up to the quad that a 16-byte load may touch (the vector-load conditions above
     // already promise that this quad is memory the caller owns).
     p.fastk = 0; p.a_bytes = 0; p.b_bytes = 0;
-    if (p.a_vec && p.b_vec && d->a_k.rpg == 0 && d->b_k.rpg == 0 && d->K > 0) {
+    // mode 2: the dW products dG^T . h, whose B operand walks a [B, T+1, H] history buffer with k = (sentence, timestep):
+    // neither operand k-contiguous, A's K axis plain, B's two-level with at least half a K step per group
+    const int bk_max = d->compute == CGN_COMPUTE_BF16 ? 64 : 32;
+    const bool grouped_b = d->b_k.rpg > 0 && d->a_k.rpg == 0 && !a_kc && !b_kc && 2 * d->b_k.rpg >= bk_max &&
+                           d->a_transform == CGN_ATRANS_NONE && d->epilogue == CGN_EPI_LINEAR;
+    if (p.a_vec && p.b_vec && d->a_k.rpg == 0 && (d->b_k.rpg == 0 || grouped_b) && d->K > 0) {
         auto last = [](const cgn_axis& ax, long n) {
             const long i = n - 1;
             return ax.rpg > 0 ? (i / ax.rpg) * ax.gs + (i % ax.rpg) * ax.stride : i * ax.stride;
@@ -171,8 +176,8 @@ static int prepare_gemm(const cgn_gemm_desc* d, GemmParams& p, bool& a_kc, bool&
         const long ea = (last(d->a_m, d->M) + last(d->a_k, d->K) + 4) / 4 * 4;
         const long eb = (last(d->b_k, d->K) + last(d->b_n, d->N) + 4) / 4 * 4;
         const long lim = (1L << 31) / 4 - 64;
-        if (ea < lim && eb < lim && d->a_k.stride < (1 << 24) && d->b_k.stride < (1 << 24)) {
-            p.fastk = 1;
+        if (ea < lim && eb < lim && d->a_k.stride < (1 << 24) && d->b_k.stride < (1 << 24) && d->b_k.gs < lim) {
+            p.fastk = grouped_b ? 2 : 1;
             p.a_bytes = (unsigned)(ea * 4);
             p.b_bytes = (unsigned)(eb * 4);
         }
@@ -207,7 +212,7 @@ static int run_gemm(void* stream, const cgn_gemm_desc* d, hipEvent_t ev_start, h
 
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)tiles, (unsigned)splitk);
-    if (vec_mode) *vec_mode = (p.a_vec ? 1 : 0) | (p.b_vec ? 2 : 0) | (p.fastk ? 4 : 0);
+    if (vec_mode) *vec_mode = (p.a_vec ? 1 : 0) | (p.b_vec ? 2 : 0) | (p.fastk << 2);
     if (ev_start && hipEventRecord(ev_start, s) != hipSuccess) return CGN_ERR_HIP_BASE + (int)hipGetLastError();
     if (d->compute == CGN_COMPUTE_BF16)
         launch_gemm_bf16ops(p, bt, a_kc, b_kc, grid, s);

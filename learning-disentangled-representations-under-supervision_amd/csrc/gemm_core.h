@@ -125,9 +125,12 @@ __device__ __forceinline__ u32x2 pack_bf16x4(const f32x4& v) {
 //   KC = true : memory is contiguous along k (row-major [rows][k]): thread = (row, k-quad), one float4 load per chunk
 //   KC = false: memory is contiguous along the row index ([k][rows]): thread = one row, lanes run along rows, scalar
 //               loads (a wave covers 64 consecutive rows = 256 contiguous bytes per k), 4 k per chunk
-template <int ROWS, bool KC, int BK, int S, bool VEC, bool EXP, bool BF, bool FK = false>
+// FK: 0 = generic two-level addressing in the K loop; 1 = fast (plain K axis); 2 = fast, two-level K axis with
+// rpg >= BK/2 (row-vector form only: the history-buffer operands of the dW products, k = (sentence, timestep))
+template <int ROWS, bool KC, int BK, int S, bool VEC, bool EXP, bool BF, int FK = 0>
 struct TileLoader {
     static_assert(!FK || VEC, "fast K addressing is built for the 16-byte load paths");
+    static_assert(FK != 2 || !KC, "the two-level fast form exists for row-contiguous operands");
     // LDS row stride in 4-byte words: BK + 4 floats, or (BF) BK + 8 bf16: 16 bytes of padding either way
     static constexpr int LDK = BF ? (BK + 8) / 2 : BK + 4;
     static constexpr int QUADS = ROWS * BK / 4;  // 4-k chunks per tile
@@ -150,6 +153,7 @@ struct TileLoader {
     __amdgpu_buffer_rsrc_t rsrc;
     int voff[FK ? (KC ? PER : KP) : 1];
     int kbytes;
+    int c0, wrap_bytes;  // FK == 2: the lane's first k within the K step; byte jump at a group boundary
     long roff[KC ? PER : 1];
     bool rok[KC ? PER : 1];
     bool rok4[4];
@@ -203,6 +207,8 @@ struct TileLoader {
         } else {
 #pragma unroll
             for (int j = 0; j < KP; ++j) voff[j] = (int)roff[0] * 4 + ((tid / RQ) * KP + j) * kbytes;
+            c0 = (tid / RQ) * KP;
+            wrap_bytes = (int)(ak.gs - (long)ak.rpg * ak.stride) * 4;
         }
     }
 
@@ -214,6 +220,22 @@ struct TileLoader {
             // 64-bit offset math, clustered between the MFMAs: 10-17 % of the kernel, tools/experiments/gemm_loop_probe).
             // Nothing is clamped: a load beyond the operand returns 0 (buffer bounds), one beyond kend but inside it reads
             // values that store<true>() masks (tiles that are stored unmasked lie wholly inside the K range).
+            if constexpr (FK == 2) {
+                // k = k0 + c, c < BK <= 2 rpg: the group and rest of k0 are scalar work, a lane crosses at most two
+                // group boundaries from there (two compares and selects per load instead of the 64-bit offset math)
+                const int ku = __builtin_amdgcn_readfirstlane(k0);
+                const int g0 = (int)(((unsigned long)(unsigned)ku * ak.magic) >> 40);
+                const int r0 = ku - g0 * ak.rpg;
+                const int soff = (int)((long)g0 * ak.gs + (long)r0 * ak.stride) * 4;
+                const int th1 = ak.rpg - r0, th2 = th1 + ak.rpg;
+#pragma unroll
+                for (int j = 0; j < KP; ++j) {
+                    const int c = c0 + j;
+                    const int w = (c >= th1 ? wrap_bytes : 0) + (c >= th2 ? wrap_bytes : 0);
+                    regs[st][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j] + w, soff, 0));
+                }
+                return;
+            }
             const int soff = __builtin_amdgcn_readfirstlane(k0) * kbytes;
             constexpr int NL = KC ? PER : KP;
 #pragma unroll
@@ -363,7 +385,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // SMB: the batched softmax-backward epilogue is compiled in (only the dlogits product's variant: inside the shared
 // variant its registers cost the vocabulary projection 10 %).
 template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK, bool SMB = false, bool BF = false,
-          bool FK = false>
+          int FK = 0>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, const int t) {
     constexpr int TW = BT / 64;  // 32x32 accumulators per wave along each dim
     constexpr int LDK = BF ? (BK + 8) / 2 : BK + 4;  // LDS row stride (4-byte words) of both operand images
@@ -390,7 +412,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
     const float a_scale = (EXP && p.dyn) ? p.dyn[0] : p.a_scale;
 
     static_assert(!FK || VEC == 3, "fast K addressing needs 16-byte loads on both operands");
-    TileLoader<BT, A_KC, BK, S, (VEC & 1) != 0, EXP, BF, FK> la;
+    TileLoader<BT, A_KC, BK, S, (VEC & 1) != 0, EXP, BF, (FK ? 1 : 0)> la;  // (FK == 2: only B's K axis is two-level)
     TileLoader<BT, B_KC, BK, S, (VEC & 2) != 0, false, BF, FK> lb;
     la.init(p.am, m0, p.M, p.a_row_param);
     lb.init(p.bn, n0, p.N, nullptr);
@@ -601,7 +623,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
 }
 
 template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK = (BT == 128 ? 16 : 32), bool SMB = false,
-          bool BF = false, bool FK = false>
+          bool BF = false, int FK = 0>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
     // Work item = (K split, tile). Default (order 2): the XCD remap runs over the tile list, m fastest (neighbouring
     // tiles share the B, usually the weight, panel). Orders 0/1 remap over the whole (split, tile) list so that an XCD
@@ -633,7 +655,7 @@ struct GemmGroup {
     int n;
 };
 
-template <int BT, bool A_KC, bool B_KC, int VEC, int S, int BK = (BT == 128 ? 16 : 32), bool BF = false, bool FK = false>
+template <int BT, bool A_KC, bool B_KC, int VEC, int S, int BK = (BT == 128 ? 16 : 32), bool BF = false, int FK = 0>
 __global__ __launch_bounds__(NT, 2) void gemm_group_kernel(const GemmGroup g) {
     int j = 0;
     while (j + 1 < g.n && (int)blockIdx.x >= g.tile_end[j]) ++j;  // block-uniform
@@ -689,7 +711,7 @@ constexpr int bk_of() {
     return BF ? (BT == 128 ? 32 : 64) : (BT == 128 ? 16 : 32);
 }
 
-template <int BT, int VEC, bool EXP, bool BF, bool FK>
+template <int BT, int VEC, bool EXP, bool BF, int FK>
 void launch_vk(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
     constexpr int S = 2;  // register stages (1, 3, 4 were swept in round 1: 2 is best or equal on every step shape)
     constexpr int BK = bk_of<BT, BF>();
@@ -719,12 +741,19 @@ void launch_vk(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t
 template <int BT, int VEC, bool EXP, bool BF>
 void launch_v(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
     if constexpr (VEC == 3) {
-        if (p.fastk) {
-            launch_vk<BT, VEC, EXP, BF, true>(p, a_kc, b_kc, grid, s);
+        if (p.fastk == 1) {
+            launch_vk<BT, VEC, EXP, BF, 1>(p, a_kc, b_kc, grid, s);
             return;
         }
+        if constexpr (!EXP) {
+            if (p.fastk == 2) {  // (prepare_gemm: neither operand k-contiguous, B's K axis two-level)
+                constexpr int BK = bk_of<BT, BF>();
+                hipLaunchKernelGGL((gemm_kernel<BT, false, false, VEC, false, 2, BK, false, BF, 2>), grid, dim3(NT), 0, s, p);
+                return;
+            }
+        }
     }
-    launch_vk<BT, VEC, EXP, BF, false>(p, a_kc, b_kc, grid, s);
+    launch_vk<BT, VEC, EXP, BF, 0>(p, a_kc, b_kc, grid, s);
 }
 
 template <int BT, bool EXP, bool BF>
@@ -751,7 +780,7 @@ void launch_gemm(const GemmParams& p, int bt, bool a_kc, bool b_kc, dim3 grid, h
     }
 }
 
-template <int VEC, bool BF, bool FK>
+template <int VEC, bool BF, int FK>
 void launch_group_vk(const GemmGroup& g, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s) {
     constexpr int BK = bk_of<64, BF>();
     if (a_kc && b_kc)
@@ -768,13 +797,13 @@ template <int VEC, bool BF>
 void launch_group_v(const GemmGroup& g, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s) {
     if constexpr (VEC == 3) {
         bool fk = true;  // fast K addressing only if every member qualifies (one kernel variant per group)
-        for (int i = 0; i < g.n; ++i) fk = fk && g.p[i].fastk;
+        for (int i = 0; i < g.n; ++i) fk = fk && g.p[i].fastk == 1;
         if (fk) {
-            launch_group_vk<VEC, BF, true>(g, a_kc, b_kc, blocks, s);
+            launch_group_vk<VEC, BF, 1>(g, a_kc, b_kc, blocks, s);
             return;
         }
     }
-    launch_group_vk<VEC, BF, false>(g, a_kc, b_kc, blocks, s);
+    launch_group_vk<VEC, BF, 0>(g, a_kc, b_kc, blocks, s);
 }
 
 template <bool BF>
