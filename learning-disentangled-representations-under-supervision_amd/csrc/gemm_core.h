@@ -328,6 +328,22 @@ struct TileLoader {
                 else
                     *reinterpret_cast<f32x4*>(dst + (r + i * RS) * LDK + q * 4) = v;
             }
+        } else if constexpr (VEC && !BF) {
+            // k-major image [BK][ROWS]: the lane's quad (4 consecutive rows of one k) goes out as ONE 16-byte write, lanes
+            // along the rows (conflict-free). The row-major image needed 4 transposing 8-byte writes per quad, 8-way
+            // bank-conflicted (rows 4 apart are 16 banks apart whatever the padding): 78 % of the TN kernel's LDS cycles.
+            const int row = 4 * (tid % RQ);
+            const int kl = (tid / RQ) * KP;
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                f32x4 v = regs[st][j];
+                if constexpr (MASK) {
+                    const bool kok = k0 + kl + j < kend;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = (rok4[i] && kok) ? v[i] : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(dst + (kl + j) * ROWS + row) = v;
+            }
         } else if constexpr (VEC) {
             const int row = 4 * (tid % RQ);
             const int kl = (tid / RQ) * KP;
@@ -349,6 +365,17 @@ struct TileLoader {
                         w[1] = v[j + 1];
                         *reinterpret_cast<f32x2*>(dst + (row + i) * LDK + kl + j) = w;
                     }
+                }
+            }
+        } else if constexpr (!BF) {
+            const int row = tid % ROWS;  // k-major image, lanes along the rows: 4-byte writes, conflict-free
+            const int kl = (tid / ROWS) * (4 * PER);
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x = regs[st][i][j];
+                    dst[(kl + 4 * i + j) * ROWS + row] = (!MASK || (rok[0] && k0 + kl + 4 * i + j < kend)) ? x : 0.f;
                 }
             }
         } else {
@@ -476,15 +503,32 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
     // lane's fragment base inside an operand image (4-byte words)
     const int a_lane = (wm * (BT / 2) + fr) * LDK + 4 * fk;
     const int b_lane = (wn * (BT / 2) + fr) * LDK + 4 * fk;
+    // A row-contiguous fp32 operand has a k-major LDS image [BK][BT] (TileLoader::store): the same 4 k per lane come
+    // from 4 reads of 4 bytes, lanes along the rows (two runs of 32 consecutive floats: conflict-free).
+    constexpr bool A_KM = !A_KC && !BF, B_KM = !B_KC && !BF;
+    const int a_lane_km = (4 * fk) * BT + wm * (BT / 2) + fr;
+    const int b_lane_km = (4 * fk) * BT + wn * (BT / 2) + fr;
     auto read_frags = [&](const float* As_, const float* Bs_, int jb, int slot) {
         // block jb: k = jb*KB .. jb*KB+KB-1; lane half fk holds 4 (fp32) / 8 (bf16) consecutive k = 4 words either way
         constexpr int WPB = BF ? 8 : 8;  // words per block per row: fp32 8 floats; bf16 16 halves = 8 words
 #pragma unroll
-        for (int i = 0; i < TW; ++i)
-            fa[slot][i] = *reinterpret_cast<const frag_t*>(As_ + a_lane + i * 32 * LDK + jb * WPB);
+        for (int i = 0; i < TW; ++i) {
+            if constexpr (A_KM) {
 #pragma unroll
-        for (int j = 0; j < TW; ++j)
-            fb[slot][j] = *reinterpret_cast<const frag_t*>(Bs_ + b_lane + j * 32 * LDK + jb * WPB);
+                for (int e = 0; e < 4; ++e) fa[slot][i][e] = As_[a_lane_km + (jb * 8 + e) * BT + i * 32];
+            } else {
+                fa[slot][i] = *reinterpret_cast<const frag_t*>(As_ + a_lane + i * 32 * LDK + jb * WPB);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+            if constexpr (B_KM) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fb[slot][j][e] = Bs_[b_lane_km + (jb * 8 + e) * BT + j * 32];
+            } else {
+                fb[slot][j] = *reinterpret_cast<const frag_t*>(Bs_ + b_lane + j * 32 * LDK + jb * WPB);
+            }
+        }
     };
     auto mfma_block = [&](int slot) {
         if constexpr (BF) {
