@@ -955,25 +955,56 @@ static bool persist2_ok(int B, int T, int H) {
     return true;
 }
 
+namespace {
+struct InitSlots {
+    float* h[LSTM_MAX_SEQ];
+    float* c[LSTM_MAX_SEQ];
+    int reverse[LSTM_MAX_SEQ];
+    int init_zero[LSTM_MAX_SEQ];
+};
+InitSlots p_init(const cgn_lstm_fwd_seq* seqs, int nseq) {
+    InitSlots q = {};
+    for (int i = 0; i < nseq; ++i) {
+        q.h[i] = seqs[i].hbuf; q.c[i] = seqs[i].cbuf; q.reverse[i] = seqs[i].reverse; q.init_zero[i] = seqs[i].init_zero;
+    }
+    return q;
+}
+// zero the initial-state slot (t = 0, or t = T of a reversed sequence) of hbuf / cbuf [B, T+1, H]; H % 4 == 0
+__global__ __launch_bounds__(256) void lstm_zero_initial_kernel(const InitSlots q, int B, int T, int H) {
+    const int s = blockIdx.y;
+    if (!q.init_zero[s]) return;
+    const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int hq = H / 4;
+    if (v >= (long)B * hq) return;
+    const int b = (int)(v / hq), j = (int)(v % hq) * 4;
+    const long off = ((long)b * (T + 1) + (q.reverse[s] ? T : 0)) * H + j;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(q.h[s] + off) = z;
+    *reinterpret_cast<f32x4*>(q.c[s] + off) = z;
+}
+}  // namespace
+
 extern "C" int cgn_lstm_seq_fwd_f32(void* stream, const cgn_lstm_fwd_seq* seqs, int32_t nseq, int32_t B, int32_t T,
                                     int32_t H) {
     CGN_CHECK_ARG(seqs && nseq >= 1 && nseq <= LSTM_MAX_SEQ);
     CGN_CHECK_ARG(B >= 0 && T >= 0 && H > 0 && H % 4 == 0);
     if (B == 0 || T == 0) return CGN_OK;
     FwdParams p;
+    bool any_zero = false;
     for (int i = 0; i < nseq; ++i) {
         const cgn_lstm_fwd_seq& s = seqs[i];
         CGN_CHECK_ARG(s.xg && s.w_hh && s.hbuf && s.cbuf && s.gates);
-        CGN_CHECK_ARG(((uintptr_t)s.hbuf % 16 == 0) && ((uintptr_t)s.w_hh % 16 == 0));
+        CGN_CHECK_ARG(((uintptr_t)s.hbuf % 16 == 0) && ((uintptr_t)s.w_hh % 16 == 0) && ((uintptr_t)s.cbuf % 16 == 0));
         p.s[i] = {s.xg, s.xg_extra, s.w_hh, s.hbuf, s.cbuf, s.gates, s.reverse, s.init_zero};
-        if (s.init_zero) {  // the step kernels read the initial-state slots: zero them here (strided [B,H] blocks)
-            const size_t off = (size_t)(s.reverse ? T : 0) * H, pitch = (size_t)(T + 1) * H * sizeof(float);
-            if (hipMemset2DAsync(s.hbuf + off, pitch, 0, (size_t)H * sizeof(float), (size_t)B, (hipStream_t)stream) !=
-                    hipSuccess ||
-                hipMemset2DAsync(s.cbuf + off, pitch, 0, (size_t)H * sizeof(float), (size_t)B, (hipStream_t)stream) !=
-                    hipSuccess)
-                return CGN_ERR_HIP_BASE + (int)hipGetLastError();
-        }
+        any_zero = any_zero || s.init_zero;
+    }
+    // The step kernels read the initial-state slots: zero them with a kernel of our own. (hipMemset2DAsync did this until
+    // round 2: as a node of a replayed hipGraph it was not reliably ordered against the step kernels around it on ROCm
+    // 7.2 - replays that followed a device synchronise drifted from the eager step and ended in NaN after ~30 steps.)
+    if (any_zero) {
+        hipLaunchKernelGGL(lstm_zero_initial_kernel, dim3(cgn_cdiv((long)B * H / 4, 256), nseq), dim3(256), 0,
+                           (hipStream_t)stream, p_init(seqs, nseq), B, T, H);
+        CGN_LAUNCH_CHECK();
     }
     p.B = B; p.T = T; p.H = H; p.nseq = nseq;
     dim3 grid(cgn_cdiv(H, 16) * cgn_cdiv(B, 16) * nseq);

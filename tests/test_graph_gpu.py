@@ -134,3 +134,32 @@ def test_data_parallel_schedule_one_rank_matches_plain_step(dev, one_rank_group,
     for (n, p), (_, q) in zip(m_e.named_parameters(), m_d.named_parameters()):
         err = (p - q).abs().max().item() / max(p.abs().max().item(), 1e-12)
         assert err <= 2e-6, (n, err)
+
+
+@pytest.mark.parametrize("branch_graphs", [True, False])
+def test_graph_replay_with_per_timestep_lstm_kernels_survives_a_mid_run_synchronise(dev, branch_graphs, monkeypatch):
+    """Shapes outside the persistent LSTM form (H > 512: BASELINE configs[3]) take one launch per timestep. Regression:
+    their initial-state slots were zeroed with hipMemset2DAsync, which as a node of a replayed hipGraph was not reliably
+    ordered against the step kernels around it (ROCm 7.2): replays issued back to back after a device synchronise
+    drifted from the eager step and reached NaN within ~30 steps (bench.py --workload cfg4). The slots are zeroed by a
+    kernel now; 24 unsynchronised replays with a synchronise after the 5th must train exactly like 25 eager steps."""
+    from ldrs_amd.hip import ops
+    from ldrs_amd.hip.graph import GraphedWakeSleep
+    monkeypatch.setattr(ops, "LSTM_PERSISTENT", False)
+    monkeypatch.setattr(ops, "LSTM_FUSE_LAYERS", False)
+    m_e, eng_e, opts_e, ocfg = _build(dev)
+    m_g, eng_g, opts_g, _ = _build(dev)
+    (d,) = _batches(ocfg, dev, 1)
+    for _ in range(25):
+        _, _, eg_e = eng_e.wake_sleep(opts_e, d, 0.88, 0.9)
+    g = GraphedWakeSleep(eng_g, opts_g, d, warmup_kld=0.88, warmup_tau=0.9, branch_graphs=branch_graphs)
+    for it in range(24):
+        _, _, eg_g = g(0.88, 0.9, totals=False)
+        if it == 4:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    assert float(eg_g[0]) == float(eg_g[0]), "NaN after replays"
+    assert abs(float(eg_g[0]) - float(eg_e[0])) <= 2e-6 * abs(float(eg_e[0])), (float(eg_g[0]), float(eg_e[0]))
+    for (n, p), (_, q) in zip(m_e.named_parameters(), m_g.named_parameters()):
+        err = (p.double() - q.double()).norm().item() / max(p.double().norm().item(), 1e-30)
+        assert err < 2e-6, (n, err)

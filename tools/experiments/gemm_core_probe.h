@@ -125,9 +125,12 @@ __device__ __forceinline__ u32x2 pack_bf16x4(const f32x4& v) {
 //   KC = true : memory is contiguous along k (row-major [rows][k]): thread = (row, k-quad), one float4 load per chunk
 //   KC = false: memory is contiguous along the row index ([k][rows]): thread = one row, lanes run along rows, scalar
 //               loads (a wave covers 64 consecutive rows = 256 contiguous bytes per k), 4 k per chunk
-template <int ROWS, bool KC, int BK, int S, bool VEC, bool EXP, bool BF, bool FK = false>
+// FK: 0 = generic two-level addressing in the K loop; 1 = fast (plain K axis); 2 = fast, two-level K axis with
+// rpg >= BK/2 (row-vector form only: the history-buffer operands of the dW products, k = (sentence, timestep))
+template <int ROWS, bool KC, int BK, int S, bool VEC, bool EXP, bool BF, int FK = 0>
 struct TileLoader {
     static_assert(!FK || VEC, "fast K addressing is built for the 16-byte load paths");
+    static_assert(FK != 2 || !KC, "the two-level fast form exists for row-contiguous operands");
     // LDS row stride in 4-byte words: BK + 4 floats, or (BF) BK + 8 bf16: 16 bytes of padding either way
     static constexpr int LDK = BF ? (BK + 8) / 2 : BK + 4;
     static constexpr int QUADS = ROWS * BK / 4;  // 4-k chunks per tile
@@ -150,6 +153,7 @@ struct TileLoader {
     __amdgpu_buffer_rsrc_t rsrc;
     int voff[FK ? (KC ? PER : KP) : 1];
     int kbytes;
+    int c0, wrap_bytes;  // FK == 2: the lane's first k within the K step; byte jump at a group boundary
     long roff[KC ? PER : 1];
     bool rok[KC ? PER : 1];
     bool rok4[4];
@@ -203,6 +207,8 @@ struct TileLoader {
         } else {
 #pragma unroll
             for (int j = 0; j < KP; ++j) voff[j] = (int)roff[0] * 4 + ((tid / RQ) * KP + j) * kbytes;
+            c0 = (tid / RQ) * KP;
+            wrap_bytes = (int)(ak.gs - (long)ak.rpg * ak.stride) * 4;
         }
     }
 
@@ -214,6 +220,22 @@ struct TileLoader {
             // 64-bit offset math, clustered between the MFMAs: 10-17 % of the kernel, tools/experiments/gemm_loop_probe).
             // Nothing is clamped: a load beyond the operand returns 0 (buffer bounds), one beyond kend but inside it reads
             // values that store<true>() masks (tiles that are stored unmasked lie wholly inside the K range).
+            if constexpr (FK == 2) {
+                // k = k0 + c, c < BK <= 2 rpg: the group and rest of k0 are scalar work, a lane crosses at most two
+                // group boundaries from there (two compares and selects per load instead of the 64-bit offset math)
+                const int ku = __builtin_amdgcn_readfirstlane(k0);
+                const int g0 = (int)(((unsigned long)(unsigned)ku * ak.magic) >> 40);
+                const int r0 = ku - g0 * ak.rpg;
+                const int soff = (int)((long)g0 * ak.gs + (long)r0 * ak.stride) * 4;
+                const int th1 = ak.rpg - r0, th2 = th1 + ak.rpg;
+#pragma unroll
+                for (int j = 0; j < KP; ++j) {
+                    const int c = c0 + j;
+                    const int w = (c >= th1 ? wrap_bytes : 0) + (c >= th2 ? wrap_bytes : 0);
+                    regs[st][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j] + w, soff, 0));
+                }
+                return;
+            }
             const int soff = __builtin_amdgcn_readfirstlane(k0) * kbytes;
             constexpr int NL = KC ? PER : KP;
 #pragma unroll
@@ -306,6 +328,22 @@ struct TileLoader {
                 else
                     *reinterpret_cast<f32x4*>(dst + (r + i * RS) * LDK + q * 4) = v;
             }
+        } else if constexpr (VEC && !BF) {
+            // k-major image [BK][ROWS]: the lane's quad (4 consecutive rows of one k) goes out as ONE 16-byte write, lanes
+            // along the rows (conflict-free). The row-major image needed 4 transposing 8-byte writes per quad, 8-way
+            // bank-conflicted (rows 4 apart are 16 banks apart whatever the padding): 78 % of the TN kernel's LDS cycles.
+            const int row = 4 * (tid % RQ);
+            const int kl = (tid / RQ) * KP;
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                f32x4 v = regs[st][j];
+                if constexpr (MASK) {
+                    const bool kok = k0 + kl + j < kend;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = (rok4[i] && kok) ? v[i] : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(dst + (kl + j) * ROWS + row) = v;
+            }
         } else if constexpr (VEC) {
             const int row = 4 * (tid % RQ);
             const int kl = (tid / RQ) * KP;
@@ -327,6 +365,17 @@ struct TileLoader {
                         w[1] = v[j + 1];
                         *reinterpret_cast<f32x2*>(dst + (row + i) * LDK + kl + j) = w;
                     }
+                }
+            }
+        } else if constexpr (!BF) {
+            const int row = tid % ROWS;  // k-major image, lanes along the rows: 4-byte writes, conflict-free
+            const int kl = (tid / ROWS) * (4 * PER);
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x = regs[st][i][j];
+                    dst[(kl + 4 * i + j) * ROWS + row] = (!MASK || (rok[0] && k0 + kl + 4 * i + j < kend)) ? x : 0.f;
                 }
             }
         } else {
@@ -363,7 +412,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // SMB: the batched softmax-backward epilogue is compiled in (only the dlogits product's variant: inside the shared
 // variant its registers cost the vocabulary projection 10 %).
 template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK, bool SMB = false, bool BF = false,
-          bool FK = false>
+          int FK = 0>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, const int t) {
     constexpr int TW = BT / 64;  // 32x32 accumulators per wave along each dim
     constexpr int LDK = BF ? (BK + 8) / 2 : BK + 4;  // LDS row stride (4-byte words) of both operand images
@@ -390,7 +439,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
     const float a_scale = (EXP && p.dyn) ? p.dyn[0] : p.a_scale;
 
     static_assert(!FK || VEC == 3, "fast K addressing needs 16-byte loads on both operands");
-    TileLoader<BT, A_KC, BK, S, (VEC & 1) != 0, EXP, BF, FK> la;
+    TileLoader<BT, A_KC, BK, S, (VEC & 1) != 0, EXP, BF, (FK ? 1 : 0)> la;  // (FK == 2: only B's K axis is two-level)
     TileLoader<BT, B_KC, BK, S, (VEC & 2) != 0, false, BF, FK> lb;
     la.init(p.am, m0, p.M, p.a_row_param);
     lb.init(p.bn, n0, p.N, nullptr);
@@ -454,15 +503,32 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
     // lane's fragment base inside an operand image (4-byte words)
     const int a_lane = (wm * (BT / 2) + fr) * LDK + 4 * fk;
     const int b_lane = (wn * (BT / 2) + fr) * LDK + 4 * fk;
+    // A row-contiguous fp32 operand has a k-major LDS image [BK][BT] (TileLoader::store): the same 4 k per lane come
+    // from 4 reads of 4 bytes, lanes along the rows (two runs of 32 consecutive floats: conflict-free).
+    constexpr bool A_KM = !A_KC && !BF, B_KM = !B_KC && !BF;
+    const int a_lane_km = (4 * fk) * BT + wm * (BT / 2) + fr;
+    const int b_lane_km = (4 * fk) * BT + wn * (BT / 2) + fr;
     auto read_frags = [&](const float* As_, const float* Bs_, int jb, int slot) {
         // block jb: k = jb*KB .. jb*KB+KB-1; lane half fk holds 4 (fp32) / 8 (bf16) consecutive k = 4 words either way
         constexpr int WPB = BF ? 8 : 8;  // words per block per row: fp32 8 floats; bf16 16 halves = 8 words
 #pragma unroll
-        for (int i = 0; i < TW; ++i)
-            fa[slot][i] = *reinterpret_cast<const frag_t*>(As_ + a_lane + i * 32 * LDK + jb * WPB);
+        for (int i = 0; i < TW; ++i) {
+            if constexpr (A_KM) {
 #pragma unroll
-        for (int j = 0; j < TW; ++j)
-            fb[slot][j] = *reinterpret_cast<const frag_t*>(Bs_ + b_lane + j * 32 * LDK + jb * WPB);
+                for (int e = 0; e < 4; ++e) fa[slot][i][e] = As_[a_lane_km + (jb * 8 + e) * BT + i * 32];
+            } else {
+                fa[slot][i] = *reinterpret_cast<const frag_t*>(As_ + a_lane + i * 32 * LDK + jb * WPB);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+            if constexpr (B_KM) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fb[slot][j][e] = Bs_[b_lane_km + (jb * 8 + e) * BT + j * 32];
+            } else {
+                fb[slot][j] = *reinterpret_cast<const frag_t*>(Bs_ + b_lane + j * 32 * LDK + jb * WPB);
+            }
+        }
     };
     auto mfma_block = [&](int slot) {
         if constexpr (BF) {
@@ -501,14 +567,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
                 __builtin_amdgcn_sched_barrier(0);  // issued BEFORE this block's MFMAs, which then cover the round trip
             }
             if (jb == 0) {
-#if ABLATE < 2
                 la.template store<MASK>(st, An, k1, kend, a_scale);
                 lb.template store<MASK>(st, An + TILE, k1, kend, 0.f);
-#endif
-#if ABLATE < 1
                 la.load(st, p.A, p.ak, k1 + S * BK, kbeg, kend);
                 lb.load(st, p.B, p.bk, k1 + S * BK, kbeg, kend);
-#endif
             }
             if (jb == NBLK - 1) {
                 // pin the order: this block's MFMAs stay BELOW the barrier and the reads behind it (left alone, the
@@ -605,8 +667,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
 }
 
 template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK = (BT == 128 ? 16 : 32), bool SMB = false,
-          bool BF = false, bool FK = false>
-__global__ __launch_bounds__(NT, PLB) void gemm_kernel(const GemmParams p) {
+          bool BF = false, int FK = 0>
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
     // Work item = (K split, tile). Default (order 2): the XCD remap runs over the tile list, m fastest (neighbouring
     // tiles share the B, usually the weight, panel). Orders 0/1 remap over the whole (split, tile) list so that an XCD
     // owns whole K ranges of a split-K product: that cuts the memory-side fetch of the three tall-K products (PMC:
@@ -637,14 +699,14 @@ struct GemmGroup {
     int n;
 };
 
-template <int BT, bool A_KC, bool B_KC, int VEC, int S, int BK = (BT == 128 ? 16 : 32), bool BF = false>
+template <int BT, bool A_KC, bool B_KC, int VEC, int S, int BK = (BT == 128 ? 16 : 32), bool BF = false, int FK = 0>
 __global__ __launch_bounds__(NT, 2) void gemm_group_kernel(const GemmGroup g) {
     int j = 0;
     while (j + 1 < g.n && (int)blockIdx.x >= g.tile_end[j]) ++j;  // block-uniform
     const int local = blockIdx.x - (j ? g.tile_end[j - 1] : 0);  // (split, tile) of member j, tile fastest
     const int ntiles = g.p[j].tiles_m * g.p[j].tiles_n;
     const int split = local / ntiles;
-    gemm_tile<BT, A_KC, B_KC, VEC, false, S, BK, false, BF>(g.p[j], split, local - split * ntiles);
+    gemm_tile<BT, A_KC, B_KC, VEC, false, S, BK, false, BF, FK>(g.p[j], split, local - split * ntiles);
 }
 
 // Sums the split-K slabs in fixed order z = 0..splitk-1 (bitwise reproducible). Slab rows are ldw = ceil4(N) floats
@@ -693,7 +755,7 @@ constexpr int bk_of() {
     return BF ? (BT == 128 ? 32 : 64) : (BT == 128 ? 16 : 32);
 }
 
-template <int BT, int VEC, bool EXP, bool BF, bool FK>
+template <int BT, int VEC, bool EXP, bool BF, int FK>
 void launch_vk(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
     constexpr int S = 2;  // register stages (1, 3, 4 were swept in round 1: 2 is best or equal on every step shape)
     constexpr int BK = bk_of<BT, BF>();
@@ -723,12 +785,19 @@ void launch_vk(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t
 template <int BT, int VEC, bool EXP, bool BF>
 void launch_v(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
     if constexpr (VEC == 3) {
-        if (p.fastk) {
-            launch_vk<BT, VEC, EXP, BF, true>(p, a_kc, b_kc, grid, s);
+        if (p.fastk == 1) {
+            launch_vk<BT, VEC, EXP, BF, 1>(p, a_kc, b_kc, grid, s);
             return;
         }
+        if constexpr (!EXP) {
+            if (p.fastk == 2) {  // (prepare_gemm: neither operand k-contiguous, B's K axis two-level)
+                constexpr int BK = bk_of<BT, BF>();
+                hipLaunchKernelGGL((gemm_kernel<BT, false, false, VEC, false, 2, BK, false, BF, 2>), grid, dim3(NT), 0, s, p);
+                return;
+            }
+        }
     }
-    launch_vk<BT, VEC, EXP, BF, false>(p, a_kc, b_kc, grid, s);
+    launch_vk<BT, VEC, EXP, BF, 0>(p, a_kc, b_kc, grid, s);
 }
 
 template <int BT, bool EXP, bool BF>
@@ -755,17 +824,30 @@ void launch_gemm(const GemmParams& p, int bt, bool a_kc, bool b_kc, dim3 grid, h
     }
 }
 
-template <int VEC, bool BF>
-void launch_group_v(const GemmGroup& g, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s) {
+template <int VEC, bool BF, int FK>
+void launch_group_vk(const GemmGroup& g, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s) {
     constexpr int BK = bk_of<64, BF>();
     if (a_kc && b_kc)
-        hipLaunchKernelGGL((gemm_group_kernel<64, true, true, VEC, 2, BK, BF>), dim3(blocks), dim3(NT), 0, s, g);
+        hipLaunchKernelGGL((gemm_group_kernel<64, true, true, VEC, 2, BK, BF, FK>), dim3(blocks), dim3(NT), 0, s, g);
     else if (a_kc && !b_kc)
-        hipLaunchKernelGGL((gemm_group_kernel<64, true, false, VEC, 2, BK, BF>), dim3(blocks), dim3(NT), 0, s, g);
+        hipLaunchKernelGGL((gemm_group_kernel<64, true, false, VEC, 2, BK, BF, FK>), dim3(blocks), dim3(NT), 0, s, g);
     else if (!a_kc && b_kc)
-        hipLaunchKernelGGL((gemm_group_kernel<64, false, true, VEC, 2, BK, BF>), dim3(blocks), dim3(NT), 0, s, g);
+        hipLaunchKernelGGL((gemm_group_kernel<64, false, true, VEC, 2, BK, BF, FK>), dim3(blocks), dim3(NT), 0, s, g);
     else
-        hipLaunchKernelGGL((gemm_group_kernel<64, false, false, VEC, 2, BK, BF>), dim3(blocks), dim3(NT), 0, s, g);
+        hipLaunchKernelGGL((gemm_group_kernel<64, false, false, VEC, 2, BK, BF, FK>), dim3(blocks), dim3(NT), 0, s, g);
+}
+
+template <int VEC, bool BF>
+void launch_group_v(const GemmGroup& g, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s) {
+    if constexpr (VEC == 3) {
+        bool fk = true;  // fast K addressing only if every member qualifies (one kernel variant per group)
+        for (int i = 0; i < g.n; ++i) fk = fk && g.p[i].fastk == 1;
+        if (fk) {
+            launch_group_vk<VEC, BF, 1>(g, a_kc, b_kc, blocks, s);
+            return;
+        }
+    }
+    launch_group_vk<VEC, BF, 0>(g, a_kc, b_kc, blocks, s);
 }
 
 template <bool BF>

@@ -10,6 +10,9 @@
 #ifndef PLB
 #define PLB 2
 #endif
+#ifndef PBK64
+#define PBK64 32
+#endif
 #ifndef PSTAGES
 #define PSTAGES 2
 #endif
@@ -43,9 +46,9 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
-        for (int w = 0; w < 10; ++w) hipLaunchKernelGGL((gemm_kernel<PTILE, true, true, 3, false, PSTAGES, (PTILE == 128 ? PBK128 : 32), false, false, true>), grid, dim3(NT), 0, 0, p);
+        for (int w = 0; w < 10; ++w) hipLaunchKernelGGL((gemm_kernel<PTILE, true, true, 3, false, PSTAGES, (PTILE == 128 ? PBK128 : PBK64), false, false, 1>), grid, dim3(NT), 0, 0, p);
         hipEventRecord(e0);
-        for (int w = 0; w < 10; ++w) hipLaunchKernelGGL((gemm_kernel<PTILE, true, true, 3, false, PSTAGES, (PTILE == 128 ? PBK128 : 32), false, false, true>), grid, dim3(NT), 0, 0, p);
+        for (int w = 0; w < 10; ++w) hipLaunchKernelGGL((gemm_kernel<PTILE, true, true, 3, false, PSTAGES, (PTILE == 128 ? PBK128 : PBK64), false, false, 1>), grid, dim3(NT), 0, 0, p);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms / 10 < best) best = ms / 10;
