@@ -668,7 +668,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
 
 template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK = (BT == 128 ? 16 : 32), bool SMB = false,
           bool BF = false, int FK = 0>
-__global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(NT, PLB) void gemm_kernel(const GemmParams p) {
     // Work item = (K split, tile). Default (order 2): the XCD remap runs over the tile list, m fastest (neighbouring
     // tiles share the B, usually the weight, panel). Orders 0/1 remap over the whole (split, tile) list so that an XCD
     // owns whole K ranges of a split-K product: that cuts the memory-side fetch of the three tall-K products (PMC:

@@ -43,6 +43,13 @@ int main(int argc, char** argv) {
     p.fastk = 1; p.a_bytes = (unsigned)((size_t)M * K * 4); p.b_bytes = (unsigned)((size_t)N * K * 4);
     p.tiles_m = (M + PTILE - 1) / PTILE; p.tiles_n = (N + PTILE - 1) / PTILE; p.order = 2; p.alpha = 1.f;
     dim3 grid(p.tiles_m * p.tiles_n, 1);
+    {
+        int nb = 0;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)gemm_kernel<PTILE, true, true, 3, false, PSTAGES, (PTILE == 128 ? PBK128 : PBK64), false, false, 1>, NT, 0);
+        hipFuncAttributes fa;
+        hipFuncGetAttributes(&fa, (const void*)gemm_kernel<PTILE, true, true, 3, false, PSTAGES, (PTILE == 128 ? PBK128 : PBK64), false, false, 1>);
+        printf("occupancy query: %d blocks/CU; regs %d, static LDS %zu, max threads %d\n", nb, fa.numRegs, fa.sharedSizeBytes, fa.maxThreadsPerBlock);
+    }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
