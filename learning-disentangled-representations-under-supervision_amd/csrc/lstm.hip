@@ -576,6 +576,283 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdPara
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The persistent recurrence for shapes with more (batch tile x unit tile) pairs than CUs, or H > 512 (BASELINE
+// configs[3]: H = 1024, B = 256): a workgroup owns RT batch tiles of 16 rows for its 16 hidden units, so
+// nseq * ceil(B / 16RT) * H/16 workgroups fit the CUs, and its weight slice (H <= 1024: 128 VGPRs per lane) still lives
+// in registers for the whole sequence. The row tiles of a step are worked off one after the other through the same
+// 32 KB reduction buffer; hand-off, counters and timeouts are those of the kernels above (one group = the workgroups
+// that share a 16RT-row batch tile). RT = 1, H <= 512 keeps the kernels above.
+// ------------------------------------------------------------------------------------------------------------------
+template <int CPW, int RT>
+__global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdParams p, unsigned* sync, unsigned* sticky) {
+    __shared__ float red[LSTM_NW][16][64];
+    __shared__ int s_ok;
+    const int B = p.B, T = p.T, H = p.H;
+    const int NJ = H / 16, NB = (B + 16 * RT - 1) / (16 * RT);
+    const int wid = blockIdx.x;
+    const int seq = wid / (NB * NJ);
+    const int bt = (wid % (NB * NJ)) / NJ, jt = wid % NJ;
+    const FwdSeq& sq = p.s[seq];
+    unsigned* cnt = sync + (seq * NB + bt) * SYNC_STRIDE;
+    unsigned* tmo = sync + p.nseq * NB * SYNC_STRIDE;
+    const int j0 = jt * 16, b0 = bt * 16 * RT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, q = lane >> 4;
+    const int nchunks = H / 16;
+    const int cpw = (nchunks + LSTM_NW - 1) / LSTM_NW;  // <= CPW (host check)
+    const int c_beg = wave * cpw;
+
+    const float* wrow = sq.w_hh + (long)(j0 + fr) * H;
+    const long gate_stride = (long)H * H;
+    f32x4 w[4][CPW];
+    int koff[CPW];
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+        const bool ok = (u < cpw) && (c_beg + u < nchunks);
+        const int kc = ok ? (c_beg + u) * 16 + q * 4 : 0;
+        koff[u] = kc * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = ld4(wrow + g * gate_stride + kc);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            w[g][u] = ok ? v : z;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t hres =
+        __builtin_amdgcn_make_buffer_rsrc((void*)sq.hbuf, 0, B * (T + 1) * H * 4, 0x00020000);
+
+    // cell-update elements of this thread (waves 0..3): row (lane>>4)*4 + wave of EVERY row tile, unit lane&15
+    const int er = wave & 3;
+    const int ej = j0 + (lane & 15);
+    const int init_slot = sq.reverse ? T : 0;
+    float c_reg[RT], pre_e[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int eb = b0 + rt * 16 + (lane >> 4) * 4 + er;
+        const int ebc = min(eb, B - 1);
+        const bool evalid = (wave < 4) && (eb < B);
+        c_reg[rt] = 0.f;
+        if (sq.init_zero) {
+            if (evalid) {
+                sq.hbuf[((long)eb * (T + 1) + init_slot) * H + ej] = 0.f;
+                sq.cbuf[((long)eb * (T + 1) + init_slot) * H + ej] = 0.f;
+            }
+        } else {
+            c_reg[rt] = sq.cbuf[((long)ebc * (T + 1) + init_slot) * H + ej];
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre_e[rt][g] = sq.xg_extra ? sq.xg_extra[(long)ebc * 4 * H + g * H + ej] : 0.f;
+    }
+
+    for (int step = 0; step < T; ++step) {
+        const int t = sq.reverse ? (T - 1 - step) : step;
+        const int slot_prev = sq.reverse ? t + 1 : t;
+        const int slot_out = sq.reverse ? t : t + 1;
+        float pre_x[RT][4];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int ebc = min(b0 + rt * 16 + (lane >> 4) * 4 + er, B - 1);
+            const float* xg = sq.xg + ((long)ebc * T + t) * 4 * H + ej;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre_x[rt][g] = xg[g * H];
+        }
+        if (step > 0) {
+            if (threadIdx.x == 0) s_ok = group_wait(cnt, (unsigned)(NJ * step), tmo, sticky) ? 1 : 0;
+            __syncthreads();
+            if (!s_ok) break;  // workgroup-uniform
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = {0.f, 0.f, 0.f, 0.f};
+            if (step > 0 || !sq.init_zero) {
+                const int bA = min(b0 + rt * 16 + fr, B - 1);
+                const int hoff = (bA * (T + 1) + slot_prev) * H * 4;
+                f32x4 a[CPW];
+#pragma unroll
+                for (int u = 0; u < CPW; ++u) a[u] = ld4_sc1(hres, hoff + koff[u]);
+#pragma unroll
+                for (int u = 0; u < CPW; ++u) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w[g][u][i], acc[g], 0, 0, 0);
+                    }
+                }
+            }
+            if (rt > 0) __syncthreads();  // the previous row tile's sums have been read
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave][g * 4 + r][lane] = acc[g][r];
+            __syncthreads();
+            const int eb = b0 + rt * 16 + (lane >> 4) * 4 + er;
+            if (wave < 4 && eb < B) {
+                float pre[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int wv = 0; wv < LSTM_NW; ++wv) v += red[wv][g * 4 + er][lane];
+                    pre[g] = v + pre_x[rt][g] + pre_e[rt][g];
+                }
+                const float ig = cgn_sigmoid(pre[0]);
+                const float fg = cgn_sigmoid(pre[1]);
+                const float gg = tanhf(pre[2]);
+                const float og = cgn_sigmoid(pre[3]);
+                const float cn = fg * c_reg[rt] + ig * gg;
+                const float hn = og * tanhf(cn);
+                c_reg[rt] = cn;
+                float* go = sq.gates + ((long)eb * T + t) * 4 * H;
+                go[ej] = ig;
+                go[H + ej] = fg;
+                go[2 * H + ej] = gg;
+                go[3 * H + ej] = og;
+                sq.cbuf[((long)eb * (T + 1) + slot_out) * H + ej] = cn;
+                st_sc1(sq.hbuf + ((long)eb * (T + 1) + slot_out) * H + ej, hn);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the arrival is signalled
+        __syncthreads();
+        if (threadIdx.x == 0 && step + 1 < T)
+            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// CPW: chunks (of 16 k over K = 4H) per wave held in registers (H <= 32 * CPW); the gradient rows are loaded CB chunks at
+// a time (32 VGPRs) so that the 128-VGPR weight slice of H = 1024 leaves room for them.
+template <int CPW, int RT>
+__global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_rt_kernel(const BwdParams p, unsigned* sync, unsigned* sticky) {
+    constexpr int CB = CPW < 8 ? CPW : 8;
+    static_assert(CPW % CB == 0 && CB % 2 == 0, "chunk batches");
+    __shared__ float red[LSTM_NW][4][64];
+    __shared__ int s_ok;
+    const int B = p.B, T = p.T, H = p.H;
+    const int K = 4 * H;
+    const int NJ = H / 16, NB = (B + 16 * RT - 1) / (16 * RT);
+    const int wid = blockIdx.x;
+    const int seq = wid / (NB * NJ);
+    const int bt = (wid % (NB * NJ)) / NJ, jt = wid % NJ;
+    const BwdSeq& sq = p.s[seq];
+    unsigned* cnt = sync + (seq * NB + bt) * SYNC_STRIDE;
+    unsigned* tmo = sync + p.nseq * NB * SYNC_STRIDE;
+    const int j0 = jt * 16, b0 = bt * 16 * RT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, q = lane >> 4;
+    const int nchunks = K / 16;
+    const int cpw = (nchunks + LSTM_NW - 1) / LSTM_NW;  // <= CPW (host check)
+    const int c_beg = wave * cpw;
+
+    f32x4 w[CPW];
+    int kbase;  // byte offset of this wave's first chunk + the lane's quad
+    {
+        kbase = (c_beg * 16 + q * 4) * 4;
+#pragma unroll
+        for (int u = 0; u < CPW; ++u) {
+            const bool ok = (u < cpw) && (c_beg + u < nchunks);
+            const int kc = ok ? (c_beg + u) * 16 + q * 4 : 0;
+            f32x4 v;
+            if (sq.w_hh) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = sq.w_hh[(long)(kc + i) * H + j0 + fr];
+            } else {
+                v = ld4(sq.w_hh_t + (long)(j0 + fr) * K + kc);
+            }
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            w[u] = ok ? v : z;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void*)sq.dgates, 0, B * T * K * 4, 0x00020000);
+
+    const int er = wave & 3;
+    const int ej = j0 + (lane & 15);
+    float dc_reg[RT], seed[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int ebc = min(b0 + rt * 16 + (lane >> 4) * 4 + er, B - 1);
+        dc_reg[rt] = sq.dc_state[(long)ebc * H + ej];
+        seed[rt] = sq.dh_seed ? sq.dh_seed[(long)ebc * H + ej] : 0.f;
+    }
+
+    for (int step = 0; step < T; ++step) {
+        const int t = sq.reverse ? step : (T - 1 - step);
+        const int t_next = sq.reverse ? t - 1 : t + 1;
+        const int slot_prev = sq.reverse ? t + 1 : t;
+        const int slot_out = sq.reverse ? t : t + 1;
+        if (step > 0) {
+            if (threadIdx.x == 0) s_ok = group_wait(cnt, (unsigned)(NJ * step), tmo, sticky) ? 1 : 0;
+            __syncthreads();
+            if (!s_ok) break;  // workgroup-uniform
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int eb = b0 + rt * 16 + (lane >> 4) * 4 + er;
+            const int ebc = min(eb, B - 1);
+            // operands of the gate-gradient update (written by earlier kernels)
+            const float* gt = sq.gates + ((long)ebc * T + t) * K + ej;
+            const float ig = gt[0], fg = gt[H], gg = gt[2 * H], og = gt[3 * H];
+            const float cprev = sq.cbuf[((long)ebc * (T + 1) + slot_prev) * H + ej];
+            const float cout = sq.cbuf[((long)ebc * (T + 1) + slot_out) * H + ej];
+            const float dhx = sq.dh_ext ? sq.dh_ext[(long)ebc * sq.dh_bs + (long)t * sq.dh_ts + ej] : 0.f;
+
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            if (step > 0) {
+                const int bA = min(b0 + rt * 16 + fr, B - 1);
+                const int aoff = (bA * T + t_next) * K * 4 + kbase;
+#pragma unroll
+                for (int c0 = 0; c0 < CPW; c0 += CB) {
+                    f32x4 a[CB];
+#pragma unroll
+                    for (int u = 0; u < CB; ++u) {
+                        // chunks beyond this wave's range hold zero weights; their (clamped) loads re-read chunk 0
+                        const int cu = (c0 + u < cpw && c_beg + c0 + u < nchunks) ? (c0 + u) : 0;
+                        a[u] = ld4_sc1(dres, aoff + cu * 64);
+                    }
+#pragma unroll
+                    for (int u = 0; u < CB; u += 2) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w[c0 + u][i], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u + 1][i], w[c0 + u + 1][i], acc1, 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            if (rt > 0) __syncthreads();  // the previous row tile's sums have been read
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc0[r] + acc1[r];
+            __syncthreads();
+            if (wave < 4 && eb < B) {
+                float dh = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < LSTM_NW; ++wv) dh += red[wv][er][lane];
+                if (step == 0) dh += seed[rt];
+                dh += dhx;
+                const float tc = tanhf(cout);
+                const float dc = dc_reg[rt] + dh * og * (1.f - tc * tc);
+                float* dg = sq.dgates + ((long)eb * T + t) * K;
+                st_sc1(dg + ej, dc * gg * ig * (1.f - ig));
+                st_sc1(dg + H + ej, dc * cprev * fg * (1.f - fg));
+                st_sc1(dg + 2 * H + ej, dc * ig * (1.f - gg * gg));
+                st_sc1(dg + 3 * H + ej, dh * tc * og * (1.f - og));
+                dc_reg[rt] = dc * fg;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0 && step + 1 < T)
+            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int eb = b0 + rt * 16 + (lane >> 4) * 4 + er;
+        if (wave < 4 && eb < B) sq.dc_state[(long)eb * H + ej] = dc_reg[rt];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Two stacked layers in ONE persistent launch (the generator's nn.LSTM(num_layers=2), model/generator.py:17-20,58).
 //
 // Layer 1 of timestep t needs h0_t, layer 0 of timestep t+1 needs h0_t too: the two layers form a wavefront, layer 1
@@ -939,6 +1216,16 @@ bool persist_ok(int nseq, int B, int T, int H) {
     return true;
 }
 
+// Row tiles per workgroup for the persistent form: 1 (the kernels without row tiling, H <= 512) when the (batch tile,
+// unit tile) pairs fit the CUs, else 2 or 4 (lstm_persist_*_rt_kernel: also H <= 1024); 0 = outside the persistent form.
+int persist_rt(int nseq, int B, int T, int H) {
+    if (nseq < 1 || nseq > LSTM_MAX_SEQ || B < 1 || T < 1 || H < 16 || H % 16 != 0 || H > 1024) return 0;
+    if ((long)B * (T + 1) * H * 4 >= (1L << 31) || (long)B * T * 4 * H * 4 >= (1L << 31)) return 0;
+    for (int rt = 1; rt <= 4; rt *= 2)
+        if ((long)nseq * cgn_cdiv(B, 16 * rt) * (H / 16) <= device_cus()) return rt;
+    return 0;
+}
+
 // scratch layout: one 128-byte line per group counter, one for the per-launch timeout word (all zeroed by every launch),
 // and, as the LAST line of whatever the caller passed, a sticky timeout flag that the library sets and never clears
 long persist_zero_bytes(int nseq, int B) { return ((long)nseq * cgn_cdiv(B, 16) + 1) * SYNC_STRIDE * 4; }
@@ -1041,11 +1328,7 @@ extern "C" int cgn_lstm_seq_bwd_f32(void* stream, const cgn_lstm_bwd_seq* seqs, 
 
 extern "C" int cgn_lstm_persistent_query(int32_t nseq, int32_t B, int32_t T, int32_t H, int64_t* sync_bytes) {
     CGN_CHECK_ARG(sync_bytes != nullptr);
-    if (!persist_ok(nseq, B, T, H)) {
-        *sync_bytes = 0;
-        return CGN_OK;
-    }
-    *sync_bytes = persist_sync_bytes(nseq, B);
+    *sync_bytes = persist_rt(nseq, B, T, H) ? persist_sync_bytes(nseq, B) : 0;
     return CGN_OK;
 }
 
@@ -1054,7 +1337,8 @@ extern "C" int cgn_lstm_seq_fwd_persistent_f32(void* stream, const cgn_lstm_fwd_
     CGN_CHECK_ARG(seqs && nseq >= 1 && nseq <= LSTM_MAX_SEQ);
     CGN_CHECK_ARG(B >= 0 && T >= 0 && H > 0);
     if (B == 0 || T == 0) return CGN_OK;
-    CGN_CHECK_ARG(persist_ok(nseq, B, T, H));
+    const int rt = persist_rt(nseq, B, T, H);
+    CGN_CHECK_ARG(rt > 0);
     const long need = persist_sync_bytes(nseq, B);
     CGN_CHECK_ARG(sync_ws && sync_ws_bytes >= need && ((uintptr_t)sync_ws % 16 == 0));
     FwdParams p;
@@ -1069,11 +1353,21 @@ extern "C" int cgn_lstm_seq_fwd_persistent_f32(void* stream, const cgn_lstm_fwd_
     if (hipMemsetAsync(sync_ws, 0, (size_t)persist_zero_bytes(nseq, B), st) != hipSuccess)
         return CGN_ERR_HIP_BASE + (int)hipGetLastError();
     unsigned* sticky = (unsigned*)((char*)sync_ws + (sync_ws_bytes / 128 - 1) * 128);
-    dim3 grid(nseq * cgn_cdiv(B, 16) * (H / 16));
-    if (H <= 256)
-        hipLaunchKernelGGL((lstm_persist_fwd_kernel<2>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws, sticky);
-    else
-        hipLaunchKernelGGL((lstm_persist_fwd_kernel<4>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws, sticky);
+    dim3 grid(nseq * cgn_cdiv(B, 16 * rt) * (H / 16));
+    unsigned* sw = (unsigned*)sync_ws;
+#define CGN_FWD_RT(CPW, RT) hipLaunchKernelGGL((lstm_persist_fwd_rt_kernel<CPW, RT>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky)
+    if (rt == 1 && H <= 256)
+        hipLaunchKernelGGL((lstm_persist_fwd_kernel<2>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky);
+    else if (rt == 1 && H <= 512)
+        hipLaunchKernelGGL((lstm_persist_fwd_kernel<4>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky);
+    else if (rt == 1) CGN_FWD_RT(8, 1);
+    else if (rt == 2 && H <= 256) CGN_FWD_RT(2, 2);
+    else if (rt == 2 && H <= 512) CGN_FWD_RT(4, 2);
+    else if (rt == 2) CGN_FWD_RT(8, 2);
+    else if (H <= 256) CGN_FWD_RT(2, 4);
+    else if (H <= 512) CGN_FWD_RT(4, 4);
+    else CGN_FWD_RT(8, 4);
+#undef CGN_FWD_RT
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }
@@ -1151,7 +1445,8 @@ extern "C" int cgn_lstm_seq_bwd_persistent_f32(void* stream, const cgn_lstm_bwd_
     CGN_CHECK_ARG(seqs && nseq >= 1 && nseq <= LSTM_MAX_SEQ);
     CGN_CHECK_ARG(B >= 0 && T >= 0 && H > 0);
     if (B == 0 || T == 0) return CGN_OK;
-    CGN_CHECK_ARG(persist_ok(nseq, B, T, H));
+    const int rt = persist_rt(nseq, B, T, H);
+    CGN_CHECK_ARG(rt > 0);
     const long need = persist_sync_bytes(nseq, B);
     CGN_CHECK_ARG(sync_ws && sync_ws_bytes >= need && ((uintptr_t)sync_ws % 16 == 0));
     BwdParams p;
@@ -1167,11 +1462,21 @@ extern "C" int cgn_lstm_seq_bwd_persistent_f32(void* stream, const cgn_lstm_bwd_
     if (hipMemsetAsync(sync_ws, 0, (size_t)persist_zero_bytes(nseq, B), st) != hipSuccess)
         return CGN_ERR_HIP_BASE + (int)hipGetLastError();
     unsigned* sticky = (unsigned*)((char*)sync_ws + (sync_ws_bytes / 128 - 1) * 128);
-    dim3 grid(nseq * cgn_cdiv(B, 16) * (H / 16));
-    if (H <= 256)
-        hipLaunchKernelGGL((lstm_persist_bwd_kernel<8>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws, sticky);
-    else
-        hipLaunchKernelGGL((lstm_persist_bwd_kernel<16>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws, sticky);
+    dim3 grid(nseq * cgn_cdiv(B, 16 * rt) * (H / 16));
+    unsigned* sw = (unsigned*)sync_ws;
+#define CGN_BWD_RT(CPW, RT) hipLaunchKernelGGL((lstm_persist_bwd_rt_kernel<CPW, RT>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky)
+    if (rt == 1 && H <= 256)
+        hipLaunchKernelGGL((lstm_persist_bwd_kernel<8>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky);
+    else if (rt == 1 && H <= 512)
+        hipLaunchKernelGGL((lstm_persist_bwd_kernel<16>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky);
+    else if (rt == 1) CGN_BWD_RT(32, 1);
+    else if (rt == 2 && H <= 256) CGN_BWD_RT(8, 2);
+    else if (rt == 2 && H <= 512) CGN_BWD_RT(16, 2);
+    else if (rt == 2) CGN_BWD_RT(32, 2);
+    else if (H <= 256) CGN_BWD_RT(8, 4);
+    else if (H <= 512) CGN_BWD_RT(16, 4);
+    else CGN_BWD_RT(32, 4);
+#undef CGN_BWD_RT
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }

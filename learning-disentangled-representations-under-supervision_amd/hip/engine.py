@@ -235,7 +235,7 @@ def lstm_run_bwd(seqs, w_hhs, dh_exts, dh_seeds, dc_states):
     s0 = seqs[0]
     dev = s0.xg.device
     descs, outs = [], []
-    persistent = ops.lstm_persistent_bytes(len(seqs), s0.B, s0.T, s0.H, dev) > 0
+    persistent = ops.lstm_persistent_group(len(seqs), s0.B, s0.T, s0.H, dev) > 0
     for s, w, ext, seed, dc in zip(seqs, w_hhs, dh_exts, dh_seeds, dc_states):
         if persistent and w.is_contiguous():
             wt = None  # the persistent kernel loads its W_hh slice once, straight from the untransposed weight

@@ -580,9 +580,17 @@ def lstm_persistent_bytes(nseq, B, T, H, dev):
     return n.value if n.value <= LSTM_SYNC_BYTES else 0
 
 
+def lstm_persistent_group(nseq, B, T, H, dev):
+    """Sequences per persistent launch: nseq when they all fit the CUs together, 1 when only one sequence at a time does
+    (row-tiled kernels at H=1024 / B=256 use every CU for one sequence), 0 = the per-timestep kernels."""
+    if lstm_persistent_bytes(nseq, B, T, H, dev):
+        return nseq
+    return 1 if nseq > 1 and lstm_persistent_bytes(1, B, T, H, dev) else 0
+
+
 def lstm_timeout_word(dev, nseq, B, T, H):
     """The timeout word of the last persistent launch of this shape on the current stream (0 = every wait was met)."""
-    n = lstm_persistent_bytes(nseq, B, T, H, dev)
+    n = lstm_persistent_bytes(lstm_persistent_group(nseq, B, T, H, dev) or nseq, B, T, H, dev)
     return int(_lstm_sync_ws(dev)[n // 4 - 64].item()) if n else 0
 
 
@@ -632,10 +640,12 @@ def lstm_seq_fwd(seqs, B, T, H):
         arr[i].hbuf, arr[i].cbuf, arr[i].gates = s["hbuf"].data_ptr(), s["cbuf"].data_ptr(), s["gates"].data_ptr()
         arr[i].reverse = 1 if s.get("reverse") else 0
         arr[i].init_zero = 1 if s.get("init_zero") else 0
-    nb = lstm_persistent_bytes(len(seqs), B, T, H, dev)
-    if nb:
+    grp = lstm_persistent_group(len(seqs), B, T, H, dev)
+    if grp:
         ws = _lstm_sync_ws(dev)
-        _call("cgn_lstm_seq_fwd_persistent_f32", dev, arr, len(seqs), B, T, H, _ptr(ws), ws.numel() * 4)
+        for i in range(0, len(seqs), grp):
+            sub = (_lib.LstmFwdSeq * grp).from_buffer(arr, i * C.sizeof(_lib.LstmFwdSeq))
+            _call("cgn_lstm_seq_fwd_persistent_f32", dev, sub, grp, B, T, H, _ptr(ws), ws.numel() * 4)
     else:
         _call("cgn_lstm_seq_fwd_f32", dev, arr, len(seqs), B, T, H)
 
@@ -645,7 +655,7 @@ def lstm_seq_bwd(seqs, B, T, H):
     reverse). w_hh (untransposed [4H,H]) is enough when the shape takes the persistent kernel."""
     arr = (_lib.LstmBwdSeq * len(seqs))()
     dev = seqs[0]["dgates"].device
-    nb = lstm_persistent_bytes(len(seqs), B, T, H, dev)
+    grp = nb = lstm_persistent_group(len(seqs), B, T, H, dev)
     for i, s in enumerate(seqs):
         w, wt = s.get("w_hh"), s.get("w_hh_t")
         _req(wt is not None or (w is not None and nb), "lstm_seq_bwd needs w_hh_t (or w_hh on the persistent path)")
@@ -676,9 +686,11 @@ def lstm_seq_bwd(seqs, B, T, H):
         arr[i].dh_seed = seed.data_ptr() if seed is not None else None
         arr[i].dgates, arr[i].dc_state = s["dgates"].data_ptr(), s["dc_state"].data_ptr()
         arr[i].reverse = 1 if s.get("reverse") else 0
-    if nb:
+    if grp:
         ws = _lstm_sync_ws(dev)
-        _call("cgn_lstm_seq_bwd_persistent_f32", dev, arr, len(seqs), B, T, H, _ptr(ws), ws.numel() * 4)
+        for i in range(0, len(seqs), grp):
+            sub = (_lib.LstmBwdSeq * grp).from_buffer(arr, i * C.sizeof(_lib.LstmBwdSeq))
+            _call("cgn_lstm_seq_bwd_persistent_f32", dev, sub, grp, B, T, H, _ptr(ws), ws.numel() * 4)
     else:
         _call("cgn_lstm_seq_bwd_f32", dev, arr, len(seqs), B, T, H)
 

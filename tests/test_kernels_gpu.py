@@ -30,15 +30,20 @@ def rnd(*shape, seed=0, scale=1.0):
 @pytest.mark.parametrize("persistent", [False, True])
 @pytest.mark.parametrize("B,T,H,Din,bidir", [(5, 4, 16, 12, True), (17, 6, 36, 23, False), (64, 3, 512, 40, True),
                                              (33, 7, 48, 20, True), (64, 21, 512, 24, False), (32, 15, 256, 24, True),
-                                             (64, 20, 512, 24, True)])
+                                             (64, 20, 512, 24, True),
+                                             # row-tiled persistent kernels: (CPW 8, RT 1), (one sequence per launch,
+                                             # RT 4), (RT 2, CPW 4), (RT 2, CPW 2, ragged last tile), (RT 4, ragged)
+                                             (64, 5, 1024, 24, False), (256, 4, 1024, 16, True),
+                                             (256, 5, 512, 16, False), (250, 3, 256, 16, True),
+                                             (200, 3, 1024, 8, False)])
 def test_lstm_fwd_bwd(dev, B, T, H, Din, bidir, persistent, monkeypatch):
     """persistent=True: the one-launch recurrence (register-resident W_hh, per-batch-tile hand-off of h_t) where the
     shape is eligible; False: one launch per timestep. Both against torch.nn.LSTM in fp64."""
     engine, ops = _mods()
     monkeypatch.setattr(ops, "LSTM_PERSISTENT", persistent)
     nseq = 2 if bidir else 1
-    eligible = ops.lstm_persistent_bytes(nseq, B, T, H, dev) > 0
-    assert eligible == (persistent and H % 16 == 0 and H <= 512)
+    eligible = ops.lstm_persistent_group(nseq, B, T, H, dev) > 0
+    assert eligible == (persistent and H % 16 == 0 and H <= 1024)
     torch.manual_seed(B + T + H)
     ref = torch.nn.LSTM(Din, H, 1, batch_first=True, bidirectional=bidir).double()
     x = rnd(B, T, Din, seed=1).double().requires_grad_(True)

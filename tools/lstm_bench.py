@@ -1,4 +1,5 @@
-"""Diagnostic: the persistent LSTM launches ALONE on the GPU (cfg2 shapes): us per launch and per timestep."""
+"""Diagnostic: the LSTM launches ALONE on the GPU: us per launch and per timestep.
+usage: lstm_bench.py [B H [T]]   (default 64 512 = cfg2; 256 1024 40 = cfg4). CGN_LSTM_PERSISTENT=0 times the per-timestep kernels."""
 import os
 import sys
 
@@ -34,8 +35,11 @@ def seqs(n, B, T, H, revs):
     return out
 
 
-B, H = 64, 512
-for name, T, revs in (("encoder biLSTM (2 sequences)", 20, (False, True)), ("one generator layer", 21, (False,))):
+B, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (64, 512)
+T0 = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+print("B %d H %d: sequences per persistent launch: encoder %d, generator layer %d" % (
+    B, H, ops.lstm_persistent_group(2, B, T0, H, dev), ops.lstm_persistent_group(1, B, T0 + 1, H, dev)))
+for name, T, revs in (("encoder biLSTM (2 sequences)", T0, (False, True)), ("one generator layer", T0 + 1, (False,))):
     ss = seqs(len(revs), B, T, H, revs)
     W = [torch.randn(4 * H, H, device=dev) / H ** 0.5 for _ in revs]
     us = timeit(lambda: engine.lstm_run_fwd(ss, W))
@@ -44,7 +48,10 @@ for name, T, revs in (("encoder biLSTM (2 sequences)", 20, (False, True)), ("one
     dcs = [torch.zeros(B, H, device=dev) for _ in revs]
     us = timeit(lambda: engine.lstm_run_bwd(ss, W, [(dh, T * H, H)] * len(revs), [None] * len(revs), dcs))
     print("%-32s bwd  %7.1f us  %5.2f us/step" % (name, us, us / T))
-T = 21
+T = T0 + 1
+if not ops.lstm2_persistent_bytes(B, T, H, dev):
+    print("two-layer wavefront form: shape not eligible; sticky timeouts:", ops.lstm_sticky_timeouts())
+    sys.exit(0)
 g0, g1 = seqs(2, B, T, H, (False, False))
 Ws = [torch.randn(4 * H, H, device=dev) / H ** 0.5 for _ in range(3)]
 bs = [torch.randn(4 * H, device=dev) * 0.1 for _ in range(2)]
