@@ -126,6 +126,13 @@ int cgn_softmax_nll_fwd_f32(void* stream, const float* logits, int64_t ld, const
                             float inv_tau, const float* dyn_inv_tau /* device, nullable: overrides inv_tau */,
                             float* lse, float* nll, float* loss);
 
+/* The sampler's learning=True output (model/cgn.py:880,901-902 with utils/beam_search.py:140-152 get_hyp_probs): the
+ * log_softmax rows (cgn.py:803) of the parent beams on the best hypothesis' back-pointer chain, picked after the search:
+ *   out[i, :] = logits[rows[i], :] - lse[rows[i]],  rows[i] in [0, n_src). logits [n_src, V] row stride ld, out row
+ * stride ldo. */
+int cgn_log_softmax_rows_f32(void* stream, const float* logits, int64_t ld, const float* lse, const int64_t* rows,
+                             int32_t n_rows, int64_t n_src, int32_t V, float* out, int64_t ldo);
+
 /* ------------------------------------------------------------------------------------------------------------
  * LSTM recurrence (nn.LSTM at model/encoder.py:17-21,40 and model/generator.py:17-20,58). The input projections
  * x·W_ihᵀ + b_ih + b_hh are cgn_gemm_f32 calls; these entry points run the T dependent steps (one launch per step,

@@ -88,6 +88,20 @@ __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, 
 
 }  // namespace
 
+// out[i, :] = logits[rows[i], :] - lse[rows[i]]: the log_softmax rows a caller picks AFTER the fact (the sampler's
+// learning=True walk-back, utils/beam_search.py:140-152); one block per picked row
+__global__ void __launch_bounds__(SM_NT) log_softmax_rows_kernel(const float* __restrict__ logits, long ld,
+                                                                  const float* __restrict__ lse,
+                                                                  const long* __restrict__ rows, long n_src, int V,
+                                                                  float* __restrict__ out, long ldo) {
+    const long r = rows[blockIdx.x];
+    if (r < 0 || r >= n_src) return;  // host validated; never index outside the source
+    const float l = lse[r];
+    const float* src = logits + r * ld;
+    float* dst = out + (long)blockIdx.x * ldo;
+    for (int v = threadIdx.x; v < V; v += SM_NT) dst[v] = src[v] - l;
+}
+
 extern "C" int cgn_softmax_nll_fwd_f32(void* stream, const float* logits, int64_t ld, const int64_t* target, int32_t M,
                                        int32_t V, float inv_tau, const float* dyn_inv_tau, float* lse, float* nll,
                                        float* loss) {
@@ -99,6 +113,18 @@ extern "C" int cgn_softmax_nll_fwd_f32(void* stream, const float* logits, int64_
                        dyn_inv_tau, lse, nll);
     CGN_LAUNCH_CHECK();
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, nll, M, 1.0f / (float)M, loss);
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}
+
+extern "C" int cgn_log_softmax_rows_f32(void* stream, const float* logits, int64_t ld, const float* lse,
+                                        const int64_t* rows, int32_t n_rows, int64_t n_src, int32_t V, float* out,
+                                        int64_t ldo) {
+    CGN_CHECK_ARG(n_rows >= 0 && V > 0 && ld >= V && ldo >= V && n_src >= 0);
+    if (n_rows == 0) return CGN_OK;
+    CGN_CHECK_ARG(logits && lse && rows && out);
+    hipLaunchKernelGGL(log_softmax_rows_kernel, dim3(n_rows), dim3(SM_NT), 0, (hipStream_t)stream, logits, (long)ld, lse,
+                       (const long*)rows, (long)n_src, V, out, (long)ldo);
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }

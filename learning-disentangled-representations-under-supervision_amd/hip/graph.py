@@ -176,47 +176,44 @@ class GraphedWakeSleep:
                 ops.KEEP = None
             ops.KEEP = []
             try:
-                if eng.dp:
-                    import gc
-                    gc.collect()
-                    torch.cuda.empty_cache()
-                    rec = _SegmentRecorder(thread_local=torch.distributed.is_initialized())
-                    eng.recorder = rec
-                    try:
-                        with torch.cuda.stream(self.stream):
+                with ops.capture_without_gc():  # a collector run inside a capture can abort the process (ops.py)
+                    if eng.dp:
+                        torch.cuda.empty_cache()
+                        rec = _SegmentRecorder(thread_local=torch.distributed.is_initialized())
+                        eng.recorder = rec
+                        try:
+                            with torch.cuda.stream(self.stream):
+                                rec.begin()
+                                try:
+                                    self.out = self._run()
+                                    rec.end()
+                                except BaseException:
+                                    rec.abort()
+                                    raise
+                        finally:
+                            eng.recorder = None
+                        self.segments = rec.segments
+                    elif overlap and branch_graphs:
+                        torch.cuda.empty_cache()
+                        rec = _BranchRecorder(self.stream, thread_local=torch.distributed.is_initialized())
+                        eng.recorder = rec
+                        try:
                             rec.begin()
                             try:
-                                self.out = self._run()
+                                with torch.cuda.stream(self.stream):
+                                    self.out = self._run()
                                 rec.end()
                             except BaseException:
                                 rec.abort()
                                 raise
-                    finally:
-                        eng.recorder = None
-                    self.segments = rec.segments
-                elif overlap and branch_graphs:
-                    import gc
-                    gc.collect()
-                    torch.cuda.empty_cache()
-                    rec = _BranchRecorder(self.stream, thread_local=torch.distributed.is_initialized())
-                    eng.recorder = rec
-                    try:
-                        rec.begin()
-                        try:
-                            with torch.cuda.stream(self.stream):
-                                self.out = self._run()
-                            rec.end()
-                        except BaseException:
-                            rec.abort()
-                            raise
-                    finally:
-                        eng.recorder = None
-                    self.branches = rec.segments
-                    self.segments = None
-                else:
-                    with torch.cuda.graph(self.graph, stream=self.stream):
-                        self.out = self._run()
-                    self.segments = [(self.graph, [])]
+                        finally:
+                            eng.recorder = None
+                        self.branches = rec.segments
+                        self.segments = None
+                    else:
+                        with torch.cuda.graph(self.graph, stream=self.stream):
+                            self.out = self._run()
+                        self.segments = [(self.graph, [])]
             finally:
                 self.keep, ops.KEEP = ops.KEEP, None  # temporaries of the captured step stay alive with the graph
         finally:

@@ -3,7 +3,9 @@
 Every function validates device/dtype/shape on the host before a kernel is launched (a faulting kernel can reset the
 whole GPU node), launches on torch's current stream and returns torch tensors that alias caller-visible memory.
 """
+import contextlib
 import ctypes as C
+import gc
 import os
 
 import torch
@@ -69,6 +71,21 @@ def workspace(device):
 # returned to torch's caching allocator before the step ends: kernels of the same step running on different streams
 # (and the nodes of a captured hipGraph) can then never see a buffer recycled under them.
 KEEP = None
+
+
+@contextlib.contextmanager
+def capture_without_gc():
+    """Stream capture must not be interrupted by Python's cyclic garbage collector: collecting an old hipGraph, event or
+    stream object (e.g. a dropped engine's captured decode graphs) issues HIP calls that are illegal while this thread
+    captures, and the runtime aborts the process. Collect first, then keep the collector off for the capture."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 def alloc(shape, dev, dtype=torch.float32):
@@ -277,6 +294,22 @@ def softmax_nll_fwd(logits, target, inv_tau, dyn=None):
                                                inv_tau, _ptr(dyn), _ptr(lse), _ptr(nll), _ptr(loss)),
                    "cgn_softmax_nll_fwd_f32")
     return lse, nll, loss
+
+
+def log_softmax_rows(logits, lse, rows):
+    """out[i] = logits[rows[i]] - lse[rows[i]] for logits [R,V] (contiguous), lse [R], rows int64 [n] (device): the
+    log_softmax rows of model/cgn.py:803 picked after the fact (sampler learning=True)."""
+    _chk_f32(logits, "logits"), _chk_f32(lse, "lse"), _chk_i64(rows, "rows")
+    if logits.dim() != 2 or not logits.is_contiguous() or not lse.is_contiguous() or lse.numel() != logits.shape[0]:
+        raise ValueError("logits must be contiguous [R,V] and lse [R]")
+    if rows.dim() != 1 or not rows.is_contiguous():
+        raise ValueError("rows must be a contiguous int64 vector")
+    R, V = logits.shape
+    out = alloc((rows.numel(), V), logits.device)
+    with torch.cuda.device(logits.device):
+        _lib.check(_lib.load().cgn_log_softmax_rows_f32(_stream(), _ptr(logits), V, _ptr(lse), _ptr(rows), rows.numel(),
+                                                        R, V, _ptr(out), V), "cgn_log_softmax_rows_f32")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -98,6 +98,7 @@ class BeamSampler:
         ops.gemm(hp, P["generator.fc.weight"].t(), logits, M=R, K=H, a_m=hax, a_k=LIN,
                  bias0=P["generator.fc.bias"])  # cgn.py:803
         lse, _, _ = ops.softmax_nll_fwd(logits, st.zero_tgt, 1.0)  # log_softmax = logits - lse
+        st.step_out = (logits, lse)  # learning=True keeps every step's rows (static addresses inside a captured step)
         ops.beam_topk(logits, lse, S, K, first, eos, pad, st.scores, st.done, st.length, st.cur, st.origin,
                       st.src_rows, st.tok_out, st.org_out)
         # cgn.py:823-838: every beam continues from its parent's state (rows of the [R,2,H] buffers, slot 1)
@@ -115,23 +116,29 @@ class BeamSampler:
             self._token_step(st, False, eos, pad)
         torch.cuda.current_stream(dev).wait_stream(stream)
         torch.cuda.synchronize(dev)
-        graphs = []
+        graphs, outs = [], []
         prev_keep, ops.KEEP = ops.KEEP, []
         try:
-            for first in (True, False):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=stream):
-                    self._token_step(st, first, eos, pad)
-                graphs.append(g)
+            with ops.capture_without_gc():
+                for first in (True, False):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=stream):
+                        self._token_step(st, first, eos, pad)
+                    graphs.append(g)
+                    outs.append(st.step_out)
             st.keep = ops.KEEP
         finally:
             ops.KEEP = prev_keep
-        st.graphs = tuple(graphs)
+        st.graphs, st.graph_outs = tuple(graphs), tuple(outs)
         st.tokens_key = (go, eos, pad)
 
-    def sample(self, seed, seq_len, beam_size, go, eos, pad, n_best=1):
+    def sample(self, seed, seq_len, beam_size, go, eos, pad, n_best=1, learning=False):
         """seed [S, Z+C] (device fp32). Returns (hyps, scores): hyps[s] = list over n_best of token lists,
-        scores[s] = the final beam scores of sentence s, descending (device tensor [K])."""
+        scores[s] = the final beam scores of sentence s, descending (device tensor [K]).
+        learning=True (cgn.py:880,901-902): returns instead, per sentence, the [len_s, V] device tensor of log_softmax
+        rows that Beam.get_hyp_probs (beam_search.py:140-152) collects: walking the back-pointers from beam 0, the
+        distribution of the PARENT beam at every step. Every step's [S*K, V] logits are kept for the walk-back
+        (seq_len * S * K * V * 4 bytes: 160 MB for 10 sentences at BASELINE configs[1])."""
         eng = self.eng
         cfg, P, dev = eng.cfg, eng.P, eng.dev
         E, H = cfg.word_embed_size, cfg.decoder_rnn_size
@@ -155,6 +162,9 @@ class BeamSampler:
         st.reset(go, pad)
         hist_tok = torch.zeros(seq_len, R, dtype=torch.int64, device=dev)
         hist_org = torch.zeros(seq_len, R, dtype=torch.int32, device=dev)
+        if learning:
+            V = cfg.word_vocab_size
+            hist_logits, hist_lse = _new((seq_len * R, V), dev), _new((seq_len * R,), dev)
         for i in range(seq_len):  # cgn.py:786
             if graphed:
                 st.graphs[0 if i == 0 else 1].replay()
@@ -162,12 +172,27 @@ class BeamSampler:
                 self._token_step(st, i == 0, eos, pad)
             hist_tok[i].copy_(st.tok_out, non_blocking=True)
             hist_org[i].copy_(st.org_out, non_blocking=True)
+            if learning:  # beam_search.py:73 `self.output_probs.append(workd_lk)`
+                lg, ls = st.graph_outs[0 if i == 0 else 1] if graphed else st.step_out
+                hist_logits[i * R:(i + 1) * R].copy_(lg, non_blocking=True)
+                hist_lse[i * R:(i + 1) * R].copy_(ls, non_blocking=True)
             if bool(st.done.all().item()):  # cgn.py:840-841 (host check per token, as in the reference)
                 break
         ops.raise_on_lstm_timeout()  # the loop has just synchronised: one more word read costs nothing
 
         # (4) package everything up, cgn.py:872-882: walk the back-pointers (Beam.get_hyp, beam_search.py:121-132)
         tok_h, org_h, len_h = hist_tok.cpu(), hist_org.cpu(), st.length.cpu().tolist()
+        if learning:
+            picks = []
+            for s in range(S):
+                k, rows = 0, []
+                for j in range(len_h[s] - 1, -1, -1):  # beam_search.py:145-150: the parent first, then its row
+                    k = int(org_h[j, s * K + k])
+                    rows.append(j * R + s * K + k)
+                picks.append(rows[::-1])
+            flat = torch.tensor([r for rows in picks for r in rows], dtype=torch.int64, device=dev)
+            lp = ops.log_softmax_rows(hist_logits, hist_lse, flat)
+            return list(torch.split(lp, [len(rows) for rows in picks]))
         sc = st.scores.clone().view(S, K)
         order = torch.sort(sc, 1, True)[1].cpu()  # sort_best (:101-103); already descending up to ties
         hyps = []

@@ -332,10 +332,9 @@ class Controlled_Generation_Sentence(nn.Module):
     def sample_from_generator(self, batch_loader, seq_len, seed, use_cuda, beam_size=10, n_best=1, samples=5,
                               learning=False):
         """cgn.py:747-921. Returns (all_sent_codes, allScores): all_sent_codes[b] = list over time of n_best-tuples of
-        word ids (the zip(*hyps) of :879), allScores[b] = the n_best best joint log-probabilities."""
-        if learning:
-            raise NotImplementedError("learning=True (per-token soft distributions, beam_search.py:140-152) is not "
-                                      "used by the training loop (train_functions.py:56 passes learning=False)")
+        word ids (the zip(*hyps) of :879), allScores[b] = the n_best best joint log-probabilities.
+        learning=True (:880,901-902): returns all_sent_probs instead: all_sent_probs[b] = the [len_b, V] device tensor of
+        log_softmax rows along the best hypothesis (Beam.get_hyp_probs, beam_search.py:140-152)."""
         if not use_cuda:
             raise RuntimeError("the sampler runs on the MI355X only (use_cuda must be True)")
         self.generator.eval()
@@ -344,6 +343,8 @@ class Controlled_Generation_Sentence(nn.Module):
         w2i = batch_loader.word_to_idx
         go, eos, pad = w2i[batch_loader.go_token], w2i[batch_loader.end_token], w2i[batch_loader.pad_token]
         seed = seed[:samples].to(eng.dev, t.float32).contiguous()
+        if learning:
+            return BeamSampler(eng).sample(seed, seq_len, beam_size, go, eos, pad, n_best=n_best, learning=True)
         hyps, scores = BeamSampler(eng).sample(seed, seq_len, beam_size, go, eos, pad, n_best=n_best)
         all_sent_codes = [list(zip(*h)) for h in hyps]
         allScores = [sc[:n_best] for sc in scores]

@@ -606,14 +606,17 @@ def make_optimizers(model):
 # seeds; here every sentence keeps its own seed. Until the first sentence finishes the two are identical.
 # Python-2 integer divisions (beam_search.py:88 `bestScoresId / num_words`) are written as floor divisions.
 # --------------------------------------------------------------------------------------------------------------
-def sample_from_generator(model, seed, seq_len, beam_size, go, eos, pad, n_best=1):
+def sample_from_generator(model, seed, seq_len, beam_size, go, eos, pad, n_best=1, learning=False):
     """seed [S, Z+C]. Returns (hyps, scores): hyps[s] = list over n_best of token lists (the walk-back of
-    Beam.get_hyp, beam_search.py:121-132), scores[s] = the beam's final scores sorted descending (sort_best :101)."""
+    Beam.get_hyp, beam_search.py:121-132), scores[s] = the beam's final scores sorted descending (sort_best :101).
+    learning=True (cgn.py:880,901-902): returns instead the list over sentences of [len_s, V] log_softmax rows collected
+    by Beam.get_hyp_probs (beam_search.py:140-152)."""
     gen, emb = model.generator, model.embedding.word_embed
     V = gen.fc.out_features
-    hyps, all_scores = [], []
+    hyps, all_scores, all_probs = [], [], []
     with torch.no_grad():
         for s in range(seed.shape[0]):
+            output_probs = []  # beam_search.py:43
             zc = seed[s:s + 1]
             scores = torch.zeros(beam_size, dtype=seed.dtype)  # beam_search.py:31
             prev_ks, next_ys = [], [torch.full((beam_size,), pad, dtype=torch.int64)]  # :34-37
@@ -624,6 +627,7 @@ def sample_from_generator(model, seed, seq_len, beam_size, go, eos, pad, n_best=
                 x = torch.cat([x, zc.expand(beam_size, -1).unsqueeze(1)], 2)  # generator.py:30-39
                 out, state = gen.rnn(x, state)  # generator.py:41
                 word_lk = F.log_softmax(gen.fc(out.squeeze(1)), dim=1)  # cgn.py:800-803  [K,V]
+                output_probs.append(word_lk)  # beam_search.py:73
                 beam_lk = word_lk + scores.unsqueeze(1) if prev_ks else word_lk[0]  # beam_search.py:76-79
                 best, best_id = beam_lk.reshape(-1).topk(beam_size, 0, True, True)  # :83
                 scores = best
@@ -643,4 +647,11 @@ def sample_from_generator(model, seed, seq_len, beam_size, go, eos, pad, n_best=
                 out_h.append(hyp[::-1])
             hyps.append(out_h)
             all_scores.append(sc)
+            k, rows = 0, []
+            for j in range(len(prev_ks) - 1, -1, -1):  # get_hyp_probs, beam_search.py:140-152
+                k = int(prev_ks[j][k])  # :148 (the parent FIRST, then its row: :149)
+                rows.append(output_probs[j][k])
+            all_probs.append(torch.stack(rows[::-1]))
+    if learning:
+        return all_probs
     return hyps, all_scores

@@ -278,3 +278,35 @@ def test_bf16_mode_decodes_identical_greedy_tokens(dev):
     assert sum(n >= 3 for n in clear_prefix) >= S // 2, clear_prefix
     print("bf16 greedy decode: %d of %d sentences identical to fp32; %d tokens compared before a near-tie" %
           (identical, S, compared))
+
+
+@pytest.mark.parametrize("graphed", [True, False])
+@pytest.mark.parametrize("S,K,eos_bias", [(6, 5, 0.0), (7, 4, 4.0), (3, 1, 0.0)])
+def test_beam_sampler_learning_returns_the_parent_beams_log_softmax_rows(dev, S, K, eos_bias, graphed, monkeypatch):
+    """learning=True (cgn.py:880,901-902; Beam.get_hyp_probs, beam_search.py:140-152): per sentence the [len, V]
+    log_softmax rows of the parent beams along beam 0's back-pointer chain, against the oracle's restatement in fp64
+    (absolute 1e-4 on log-probabilities; same lengths, i.e. the same early finishes)."""
+    from ldrs_amd.hip import sampler as hs
+    orig_init = hs.BeamSampler.__init__
+    monkeypatch.setattr(hs.BeamSampler, "__init__", lambda self, eng, use_graph=True: orig_init(self, eng, graphed))
+    cfg, ocfg, oracle, model, handler = _build(dev, eos_bias)
+    V = ocfg.word_vocab_size
+    pad, go, eos = V - 3, V - 2, V - 1
+    g = torch.Generator().manual_seed(100 + S)
+    seed = torch.cat([torch.randn(S, ocfg.latent_variable_size, generator=g),
+                      torch.bernoulli(torch.full((S, 1), 0.5), generator=g)], 1)
+    ref = O.sample_from_generator(oracle, seed.double(), ocfg.max_seq_len, K, go, eos, pad, learning=True)
+    got = model.sample_from_generator(handler.gen_batch_loader, cfg.max_seq_len, seed, True, beam_size=K, samples=S,
+                                      learning=True)
+    assert len(got) == S
+    for s in range(S):
+        assert tuple(got[s].shape) == tuple(ref[s].shape) == (ref[s].shape[0], V), (s, got[s].shape, ref[s].shape)
+        err = (got[s].double().cpu() - ref[s]).abs().max().item()
+        assert err <= 1e-4, (s, err)
+        # each row is a normalised distribution
+        assert (got[s].double().exp().sum(1) - 1).abs().max().item() <= 1e-4
+    # a second call on the same (S, K) state reuses the captured graphs and gives the same rows
+    again = model.sample_from_generator(handler.gen_batch_loader, cfg.max_seq_len, seed, True, beam_size=K, samples=S,
+                                        learning=True)
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)
