@@ -161,8 +161,9 @@ int cgn_lstm_seq_fwd_f32(void* stream, const cgn_lstm_fwd_seq* seqs /* host */, 
  * per-group arrival counter (csrc/lstm.hip). Replaces the same reference call sites as cgn_lstm_seq_fwd/bwd_f32
  * (nn.LSTM at model/encoder.py:17-21,40 and model/generator.py:17-20,58), same buffers and results.
  * cgn_lstm_persistent_query: *sync_bytes = size of the caller-owned, 16-byte aligned device scratch `sync_ws` the
- * launch needs, or 0 when the shape is not eligible (H % 16, H <= 512, nseq * ceil(B/16) * H/16 workgroups <= CUs of
- * the current device): use the step kernels then. Layout: sync_bytes - 128 bytes of counters plus the launch's timeout
+ * launch needs, or 0 when the shape is not eligible (H % 16, H <= 1024, nseq * ceil(B/(16*RT)) * H/16 workgroups <= CUs
+ * of the current device for RT = 1, 2 or 4 row tiles per workgroup; H > 512 always takes the row-tiled kernels): use
+ * the step kernels then, or one launch per sequence when a single sequence is eligible. Layout: sync_bytes - 128 bytes of counters plus the launch's timeout
  * word, zeroed by the library on the stream before each launch - after the stream has drained, word
  * (sync_bytes/4 - 64) is non-zero iff a bounded wait of THAT launch ran out (results invalid); and the LAST whole
  * 128-byte line of the buffer actually passed (sync_ws_bytes) is a STICKY timeout flag: set by any launch whose wait
