@@ -433,8 +433,14 @@ class CGNStep:
                 self.flush()
         if param_grads and self.overlap and not self.dp and getattr(self.recorder, "parallel", False):
             self._deferring = True  # the highway's dW products wait for the end of the dX chain (one more branch graph)
+        turn = [0]
+
+        def hw_later(fn):  # the two layers' dW products on different side streams: each one's reduce / column-sum kernels
+            self.later(turn[0] % 2, fn)  # run beside the other's GEMM (-0.6 % of the step; an early partial Adam here: +0.5 %)
+            turn[0] += 1
+
         return engine.highway_bwd(es["hw_saved"], self._hw_layers(P), dhw, self._hw_layers(G) if param_grads else None,
-                                  need_dx=True, later=lambda fn: self.later(0, fn))
+                                  need_dx=True, later=hw_later)
 
     def total_losses(self, ce, kld, c_loss, z_loss, kld_coeff, use_disc=True, calc_z_loss=False):
         """total_encoder_loss, total_generator_loss of cgn.py:1151-1152 from their parts (device scalars)."""
