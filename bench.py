@@ -299,21 +299,45 @@ def main():
         print(json.dumps(out), flush=True)
 
     def write_gemm_table(path, summary, peak, ms_step):
+        """Per-shape table + a four-factor model of each product's fraction of peak: the kernel's steady-state rate
+        (measured at 4096^3: 0.92 of peak for the 128-tile, 0.86 for the 64-tile) x balance (tiles per CU / its ceiling:
+        the CUs that get one tile more set the makespan) x pad (M*N / the tile grid's area) x K share (K steps per tile
+        against a fixed per-tile cost worth 8 (128-tile) / 4 (64-tile) K steps: prologue loads + epilogue)."""
+        import math
+        import re
         passes = summary["passes"]
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
         rows = sorted(summary["by_shape"].items(), key=lambda kv: -kv[1][1])
         with open(path, "w") as f:
             f.write("# per-shape table of the step's GEMM products (%s, %s): HIP events directly around each MFMA kernel\n"
-                    "# launch (split-K reduce launches excluded), %d instrumented steps; step time %.3f ms\n" %
-                    (args.workload, args.compute, passes, ms_step))
-            f.write("%-62s %2s %6s %6s %6s %5s %8s %8s %6s\n" % ("kernel symbol", "sk", "M", "N", "K", "n/st", "us", "TFLOP/s",
-                                                               "frac"))
+                    "# launch (split-K reduce launches excluded), %d instrumented steps; step time %.3f ms\n"
+                    "# model = steady-state rate (0.92 | 0.86 of peak at 4096^3) x balance (tiles/CU over its ceiling, %d CUs)\n"
+                    "#         x pad (M*N over the tile grid's area) x kshare (K steps per tile / (K steps + 8 | 4 of fixed cost))\n" %
+                    (args.workload, args.compute, passes, ms_step, cus))
+            f.write("%-62s %2s %6s %6s %6s %5s %8s %8s %6s | %6s %7s %5s %5s %6s %6s\n" % (
+                "kernel symbol", "sk", "M", "N", "K", "n/st", "us", "TFLOP/s", "frac", "tiles", "per CU", "bal", "pad",
+                "kshare", "model"))
             tot = 0.0
             for (sym, sk, M, N, K), (cnt, t) in rows:
                 us = 1e3 * t / cnt
                 tf = 2.0 * M * N * K / us / 1e6
                 tot += t / passes
-                f.write("%-62s %2d %6d %6d %6d %5.1f %8.1f %8.1f %6.3f\n" % (gemm_symbol(sym).replace("cgn_gemm::", ""), sk, M,
-                                                                            N, K, cnt / passes, us, tf, tf / peak))
+                name = gemm_symbol(sym).replace("cgn_gemm::", "")
+                m = re.match(r"gemm_(?:group_)?kernel<(\d+)", name)
+                bt = int(m.group(1)) if m else 64
+                bf = args.compute == "bf16"  # (the model's constants are fp32 measurements: no model column then)
+                bk = (16 if bt == 128 else 32) * (2 if bf else 1)
+                tm, tn = math.ceil(M / bt), math.ceil(N / bt)
+                tiles = tm * tn * max(sk, 1)
+                per_cu = tiles / cus
+                bal = per_cu / math.ceil(per_cu)
+                pad = M * N / float(tm * bt * tn * bt)
+                ksteps = K / max(sk, 1) / bk
+                kshare = ksteps / (ksteps + (8 if bt == 128 else 4))
+                model = (0.92 if bt == 128 else 0.86) * bal * pad * kshare
+                f.write("%-62s %2d %6d %6d %6d %5.1f %8.1f %8.1f %6.3f | %6d %7.2f %5.2f %5.2f %6.2f %6.2f\n" % (
+                    name, sk, M, N, K, cnt / passes, us, tf, tf / peak, tiles, per_cu, bal, pad, kshare,
+                    model if not bf else float("nan")))
             f.write("# per symbol\n")
             for sym, (cnt, t, fl) in sorted(summary["by_sym"].items(), key=lambda kv: -kv[1][1]):
                 f.write("%-62s launches/step %5.1f  us/step %8.1f  TFLOP/s %7.1f  frac %5.3f\n" %
