@@ -54,6 +54,13 @@ typedef struct cgn_axis {
 #define CGN_COMPUTE_F32 0
 #define CGN_COMPUTE_BF16 1
 
+/* cgn_gemm_desc.storage bits: bf16 STORAGE of the logits-sized tensors in the optional bf16 mode (compute must be
+ * CGN_COMPUTE_BF16). Everything not named here stays fp32 in memory. */
+#define CGN_STORE_A_BF16 1  /* A is bf16 [M][K], k-contiguous: a_k = {1,0,0}, a_m = {row stride in bf16 elements, 0, 0}
+                             * with stride % 8 == 0, K % 8 == 0, A 16-byte aligned; B must allow 16-byte loads */
+#define CGN_STORE_C_BF16 2  /* C is bf16 (ldc in bf16 elements); no split-K (tall-K products keep fp32 C), beta == 0 */
+#define CGN_STORE_EP_BF16 4 /* CGN_EPI_SOFTMAX_BWD: ep_logits is bf16 (ep_ld in bf16 elements); may alias C */
+
 #define CGN_EPI_LINEAR 0      /* C = alpha*acc + beta*C + bias0[n] + bias1[n] */
 #define CGN_EPI_SOFTMAX_BWD 1 /* see cgn_gemm_desc.ep_* */
 
@@ -93,7 +100,11 @@ typedef struct cgn_gemm_desc {
      * and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation. Memory operands, bias, epilogue, split-K
      * slabs and C stay fp32 in both modes. */
     int32_t compute;
-    int32_t reserved0; /* must be 0 */
+    int32_t storage; /* CGN_STORE_* bits, 0 = every tensor fp32 */
+    /* CGN_EPI_SOFTMAX_BWD with CGN_STORE_C_BF16 only, nullable: a transposed bf16 copy of C, c_t[n * ld_ct + m] — the
+     * k-contiguous A operand of the weight-gradient product dW_fc = dlogitsᵀ · h (model/generator.py:22,61 backward). */
+    void* c_t;
+    int64_t ld_ct;
 } cgn_gemm_desc;
 
 int cgn_gemm_f32(void* stream, const cgn_gemm_desc* desc /* host */);
@@ -125,6 +136,11 @@ int cgn_gemm_timed_f32(void* stream, const cgn_gemm_desc* desc /* host */, void*
 int cgn_softmax_nll_fwd_f32(void* stream, const float* logits, int64_t ld, const int64_t* target, int32_t M, int32_t V,
                             float inv_tau, const float* dyn_inv_tau /* device, nullable: overrides inv_tau */,
                             float* lse, float* nll, float* loss);
+/* The same over logits stored as bf16 (written by cgn_gemm_f32 with CGN_STORE_C_BF16; ld in bf16 elements); lse, nll and
+ * the loss stay fp32. model/cgn.py:1086-1092 in the optional bf16 mode with bf16 storage. */
+int cgn_softmax_nll_fwd_bf16(void* stream, const void* logits, int64_t ld, const int64_t* target, int32_t M, int32_t V,
+                             float inv_tau, const float* dyn_inv_tau /* device, nullable: overrides inv_tau */,
+                             float* lse, float* nll, float* loss);
 
 /* The sampler's learning=True output (model/cgn.py:880,901-902 with utils/beam_search.py:140-152 get_hyp_probs): the
  * log_softmax rows (cgn.py:803) of the parent beams on the best hypothesis' back-pointer chain, picked after the search:
@@ -346,6 +362,9 @@ int cgn_reparam_kld_bwd_f32(void* stream, const float* mulv, const float* eps, c
 /* out[c] = beta*out[c] + sum_r x[r,c] (bias gradients); workspace >= 64*C floats. */
 int cgn_colsum_f32(void* stream, const float* x, int64_t ld, int32_t R, int32_t C, float beta, float* out,
                    float* workspace, int64_t workspace_bytes);
+/* The same over a bf16 matrix (the bf16 mode's dlogits, cgn_gemm_desc.storage): generator.fc bias gradient. */
+int cgn_colsum_bf16(void* stream, const void* x, int64_t ld, int32_t R, int32_t C, float beta, float* out,
+                    float* workspace, int64_t workspace_bytes);
 /* out[b,c] = sum_t x[b,t,c]. */
 int cgn_sum_time_f32(void* stream, const float* x, int32_t B, int32_t T, int32_t C, float* out);
 /* out[r] = sum_c a[r,c]*b[r,c]. */

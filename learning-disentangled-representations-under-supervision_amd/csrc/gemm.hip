@@ -100,7 +100,7 @@ int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out
 
 }  // namespace
 
-extern "C" int cgn_abi_version(void) { return 3; }
+extern "C" int cgn_abi_version(void) { return 4; }
 
 extern "C" void cgn_debug_set_stages(int v) {
     g_stages = v & 15;  // kept for ABI stability: the stage count is fixed at 2 since round 1
@@ -140,6 +140,16 @@ static int prepare_gemm(const cgn_gemm_desc* d, GemmParams& p, bool& a_kc, bool&
         CGN_CHECK_ARG(d->ep_logits && d->ep_lse && d->ep_rowdot && d->ep_target && d->ep_ld >= d->N);
     CGN_CHECK_ARG(d->force_tile == 0 || d->force_tile == 64 || d->force_tile == 128);
     CGN_CHECK_ARG(d->compute == CGN_COMPUTE_F32 || d->compute == CGN_COMPUTE_BF16);
+    const bool a16 = (d->storage & CGN_STORE_A_BF16) != 0, c16 = (d->storage & CGN_STORE_C_BF16) != 0;
+    const bool ep16 = (d->storage & CGN_STORE_EP_BF16) != 0;
+    CGN_CHECK_ARG((d->storage & ~(CGN_STORE_A_BF16 | CGN_STORE_C_BF16 | CGN_STORE_EP_BF16)) == 0);
+    CGN_CHECK_ARG(d->storage == 0 || d->compute == CGN_COMPUTE_BF16);
+    if (a16)  // a plain k-contiguous bf16 matrix whose rows start on 16-byte boundaries
+        CGN_CHECK_ARG(d->a_k.stride == 1 && d->a_k.rpg == 0 && d->a_m.rpg == 0 && d->a_m.stride % 8 == 0 &&
+                      d->a_m.stride >= d->K && d->K % 8 == 0 && d->K > 0 && (uintptr_t)d->A % 16 == 0);
+    if (c16) CGN_CHECK_ARG(d->beta == 0.f && (uintptr_t)d->C % 2 == 0);
+    if (ep16) CGN_CHECK_ARG(d->epilogue == CGN_EPI_SOFTMAX_BWD);
+    if (d->c_t) CGN_CHECK_ARG(c16 && d->epilogue == CGN_EPI_SOFTMAX_BWD && d->ld_ct >= d->M);
     // an operand is "k-contiguous" when its k stride is 1; otherwise lanes run along its row index
     a_kc = d->a_k.stride == 1 || d->a_m.stride != 1;
     b_kc = d->b_k.stride == 1 || d->b_n.stride != 1;
@@ -154,11 +164,18 @@ static int prepare_gemm(const cgn_gemm_desc* d, GemmParams& p, bool& a_kc, bool&
     p.a_transform = d->a_transform; p.epilogue = d->epilogue;
     p.alpha = d->alpha; p.beta = d->beta; p.a_scale = d->a_scale;
     p.ep_inv_tau = d->ep_inv_tau; p.ep_ce_scale = d->ep_ce_scale;
+    p.a16 = a16; p.c16 = c16; p.ep16 = ep16; p.ct = d->c_t; p.ldct = d->ld_ct;
     // 16-byte loads run along the operand's contiguous axis: k for a k-contiguous operand, the row index otherwise
     p.a_vec = ((uintptr_t)d->A % 16 == 0) &&
               (a_kc ? axis_vec_ok(d->a_k, d->a_m, d->K) : axis_vec_ok(d->a_m, d->a_k, d->M));
     p.b_vec = ((uintptr_t)d->B % 16 == 0) &&
               (b_kc ? axis_vec_ok(d->b_k, d->b_n, d->K) : axis_vec_ok(d->b_n, d->b_k, d->N));
+    if (a16) {
+        // the kernel addresses a bf16 A in 4-byte words (gemm_core.h TileLoader SRC16): strides in words, k in pairs
+        CGN_CHECK_ARG(p.b_vec);
+        p.a_vec = 1;
+        p.am.stride = d->a_m.stride / 2;
+    }
     // fast K addressing: plain K axes, 16-byte loads on both operands, both operands inside 2 GB. An operand's bound is
     // its last addressed element rounded up to the quad that a 16-byte load may touch (the vector-load conditions above
     // already promise that this quad is memory the caller owns).
@@ -173,7 +190,9 @@ static int prepare_gemm(const cgn_gemm_desc* d, GemmParams& p, bool& a_kc, bool&
             const long i = n - 1;
             return ax.rpg > 0 ? (i / ax.rpg) * ax.gs + (i % ax.rpg) * ax.stride : i * ax.stride;
         };
-        const long ea = (last(d->a_m, d->M) + last(d->a_k, d->K) + 4) / 4 * 4;
+        // (bf16 A: the span in 4-byte words, rows are whole quads of words: K % 8 == 0)
+        const long ea = a16 ? (long)(d->M - 1) * (d->a_m.stride / 2) + d->K / 2
+                            : (last(d->a_m, d->M) + last(d->a_k, d->K) + 4) / 4 * 4;
         const long eb = (last(d->b_k, d->K) + last(d->b_n, d->N) + 4) / 4 * 4;
         const long lim = (1L << 31) / 4 - 64;
         if (ea < lim && eb < lim && d->a_k.stride < (1 << 24) && d->b_k.stride < (1 << 24) && d->b_k.gs < lim) {
@@ -203,6 +222,10 @@ static int run_gemm(void* stream, const cgn_gemm_desc* d, hipEvent_t ev_start, h
         const int rc = plan_gemm(d, &bt, &splitk, &kps);
         if (rc) return rc;
     }
+    if (p.c16 && splitk > 1) {  // a bf16 C is written by the product kernel itself: no slabs, no reduce pass
+        splitk = 1;
+        kps = cgn_cdiv(d->K > 0 ? d->K : 1, KROUND) * KROUND;
+    }
     p.tiles_m = cgn_cdiv(d->M, bt);
     p.tiles_n = cgn_cdiv(d->N, bt);
     const long tiles = (long)p.tiles_m * p.tiles_n;
@@ -214,7 +237,9 @@ static int run_gemm(void* stream, const cgn_gemm_desc* d, hipEvent_t ev_start, h
     dim3 grid((unsigned)tiles, (unsigned)splitk);
     if (vec_mode) *vec_mode = (p.a_vec ? 1 : 0) | (p.b_vec ? 2 : 0) | (p.fastk << 2);
     if (ev_start && hipEventRecord(ev_start, s) != hipSuccess) return CGN_ERR_HIP_BASE + (int)hipGetLastError();
-    if (d->compute == CGN_COMPUTE_BF16)
+    if (p.a16)
+        launch_gemm_a16(p, bt, b_kc, grid, s);
+    else if (d->compute == CGN_COMPUTE_BF16)
         launch_gemm_bf16ops(p, bt, a_kc, b_kc, grid, s);
     else
         launch_gemm_f32ops(p, bt, a_kc, b_kc, grid, s);
@@ -251,7 +276,7 @@ extern "C" int cgn_gemm_group_f32(void* stream, const cgn_gemm_desc* descs, int3
         bool a_kc = false, b_kc = false;
         const int rc = prepare_gemm(d, p, a_kc, b_kc);
         if (rc) return rc;
-        CGN_CHECK_ARG(d->a_transform == CGN_ATRANS_NONE && d->epilogue == CGN_EPI_LINEAR);
+        CGN_CHECK_ARG(d->a_transform == CGN_ATRANS_NONE && d->epilogue == CGN_EPI_LINEAR && d->storage == 0);
         if (i == 0) bf16 = d->compute == CGN_COMPUTE_BF16;
         CGN_CHECK_ARG((d->compute == CGN_COMPUTE_BF16) == bf16);  // one operand type per group
         if (d->M == 0 || d->N == 0) continue;

@@ -77,17 +77,31 @@ struct GemmParams {
     // offset is fixed for the whole K loop and the K position is a scalar (buffer loads: voffset + soffset)
     int fastk;
     unsigned a_bytes, b_bytes;  // bounds of the two buffer resources (loads beyond return 0)
+    // bf16 STORAGE (cgn_gemm_desc.storage): A is a k-contiguous bf16 matrix (the kernel then addresses it in 4-byte words:
+    // am/ak strides and the K positions handed to A's loader are in WORDS = pairs of k); C / ep_logits hold bf16;
+    // ct = optional transposed bf16 copy of C (ct[n * ldct + m])
+    int a16, c16, ep16;
+    void* ct;
+    long ldct;
 };
 
 constexpr int g_unroll_mult = 2;
 constexpr int KROUND = 32;  // split-K ranges start on multiples of 32 (aligned k quads; the fp32 BKs divide it)
 constexpr int NT = 256;
 
+__device__ __forceinline__ float ld_bf16(const void* base, long i) {
+    return __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(base)[i] << 16);
+}
+__device__ __forceinline__ void st_bf16(void* base, long i, float v) {
+    reinterpret_cast<__bf16*>(base)[i] = (__bf16)v;  // round to nearest even
+}
+
 __device__ __forceinline__ float apply_epilogue(const GemmParams& p, int row, int col, float acc) {
     if (p.epilogue == CGN_EPI_SOFTMAX_BWD) {
         const float inv_tau = p.dyn ? p.dyn[0] : p.ep_inv_tau;
         const float ce_scale = p.dyn ? p.dyn[1] : p.ep_ce_scale;
-        const float pr = __expf(p.ep_logits[(long)row * p.ep_ld + col] * inv_tau - p.ep_lse[row]);
+        const long li = (long)row * p.ep_ld + col;
+        const float pr = __expf((p.ep16 ? ld_bf16(p.ep_logits, li) : p.ep_logits[li]) * inv_tau - p.ep_lse[row]);
         const float onehot = (p.ep_target[row] == (int64_t)col) ? 1.f : 0.f;
         return pr * (acc - p.ep_rowdot[row]) * inv_tau + ce_scale * (pr - onehot);
     }
@@ -127,8 +141,12 @@ __device__ __forceinline__ u32x2 pack_bf16x4(const f32x4& v) {
 //               loads (a wave covers 64 consecutive rows = 256 contiguous bytes per k), 4 k per chunk
 // FK: 0 = generic two-level addressing in the K loop; 1 = fast (plain K axis); 2 = fast, two-level K axis with
 // rpg >= BK/2 (row-vector form only: the history-buffer operands of the dW products, k = (sentence, timestep))
-template <int ROWS, bool KC, int BK, int S, bool VEC, bool EXP, bool BF, int FK = 0>
+// SRC16: the operand is a k-contiguous bf16 matrix addressed in 4-byte words (BK, strides and k positions count WORDS =
+// pairs of k; BF is false: a loaded quad of words IS 8 consecutive bf16 of the bf16 LDS image, whose row stride
+// (BK_elements + 8) / 2 words equals this loader's BK + 4). Only the exp transform looks inside a word.
+template <int ROWS, bool KC, int BK, int S, bool VEC, bool EXP, bool BF, int FK = 0, bool SRC16 = false>
 struct TileLoader {
+    static_assert(!SRC16 || (KC && VEC && !BF), "bf16 storage: k-contiguous, 16-byte loads, raw copy into the bf16 image");
     static_assert(!FK || VEC, "fast K addressing is built for the 16-byte load paths");
     static_assert(FK != 2 || !KC, "the two-level fast form exists for row-contiguous operands");
     // LDS row stride in 4-byte words: BK + 4 floats, or (BF) BK + 8 bf16: 16 bytes of padding either way
@@ -319,7 +337,14 @@ struct TileLoader {
                     float x = v[j];
                     // hardware exponential (v_exp_f32 on the base-2 argument): ~1e-6 relative, two instructions
                     // instead of expf's ~15 in the loop that feeds the MFMAs (x <= 0 here: x*scale - lse)
-                    if constexpr (EXP) x = __expf(x * scale - rparam[i]);
+                    if constexpr (EXP && SRC16) {
+                        const unsigned w = __builtin_bit_cast(unsigned, x);
+                        const float lo = __expf(__builtin_bit_cast(float, w << 16) * scale - rparam[i]);
+                        const float hi = __expf(__builtin_bit_cast(float, w & 0xffff0000u) * scale - rparam[i]);
+                        x = __builtin_bit_cast(float, pack_bf16x2(lo, hi));
+                    } else if constexpr (EXP) {
+                        x = __expf(x * scale - rparam[i]);
+                    }
                     if constexpr (MASK) x = (rok[i] && k + j < kend) ? x : 0.f;
                     v[j] = x;
                 }
@@ -412,8 +437,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // SMB: the batched softmax-backward epilogue is compiled in (only the dlogits product's variant: inside the shared
 // variant its registers cost the vocabulary projection 10 %).
 template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK, bool SMB = false, bool BF = false,
-          int FK = 0>
+          int FK = 0, bool A16 = false>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, const int t) {
+    static_assert(!A16 || (BF && A_KC && (VEC & 1)), "bf16-stored A: bf16 MFMA operands, k-contiguous, 16-byte loads");
     constexpr int TW = BT / 64;  // 32x32 accumulators per wave along each dim
     constexpr int LDK = BF ? (BK + 8) / 2 : BK + 4;  // LDS row stride (4-byte words) of both operand images
     // One LDS array (both operands, two buffers): keeps every carve offset explicit and 16-byte aligned.
@@ -439,7 +465,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
     const float a_scale = (EXP && p.dyn) ? p.dyn[0] : p.a_scale;
 
     static_assert(!FK || VEC == 3, "fast K addressing needs 16-byte loads on both operands");
-    TileLoader<BT, A_KC, BK, S, (VEC & 1) != 0, EXP, BF, (FK ? 1 : 0)> la;  // (FK == 2: only B's K axis is two-level)
+    // (FK == 2: only B's K axis is two-level.) A16: A's loader works in words, KA = 2 k per word
+    constexpr int KA = A16 ? 2 : 1;
+    TileLoader<BT, A_KC, BK / KA, S, (VEC & 1) != 0, EXP, BF && !A16, (FK ? 1 : 0), A16> la;
     TileLoader<BT, B_KC, BK, S, (VEC & 2) != 0, false, BF, FK> lb;
     la.init(p.am, m0, p.M, p.a_row_param);
     lb.init(p.bn, n0, p.N, nullptr);
@@ -482,12 +510,12 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
     if (nk > 0) {
 #pragma unroll
         for (int j = 0; j < S; ++j) {
-            la.load(j, p.A, p.ak, kbeg + j * BK, kbeg, kend);
+            la.load(j, p.A, p.ak, (kbeg + j * BK) / KA, kbeg / KA, kend / KA);
             lb.load(j, p.B, p.bk, kbeg + j * BK, kbeg, kend);
         }
-        la.template store<true>(0, lds, kbeg, kend, a_scale);
+        la.template store<true>(0, lds, kbeg / KA, kend / KA, a_scale);
         lb.template store<true>(0, lds + TILE, kbeg, kend, 0.f);
-        la.load(0, p.A, p.ak, kbeg + S * BK, kbeg, kend);
+        la.load(0, p.A, p.ak, (kbeg + S * BK) / KA, kbeg / KA, kend / KA);
         lb.load(0, p.B, p.bk, kbeg + S * BK, kbeg, kend);
     }
     __syncthreads();
@@ -567,9 +595,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
                 __builtin_amdgcn_sched_barrier(0);  // issued BEFORE this block's MFMAs, which then cover the round trip
             }
             if (jb == 0) {
-                la.template store<MASK>(st, An, k1, kend, a_scale);
+                la.template store<MASK>(st, An, k1 / KA, kend / KA, a_scale);
                 lb.template store<MASK>(st, An + TILE, k1, kend, 0.f);
-                la.load(st, p.A, p.ak, k1 + S * BK, kbeg, kend);
+                la.load(st, p.A, p.ak, (k1 + S * BK) / KA, kbeg / KA, kend / KA);
                 lb.load(st, p.B, p.bk, k1 + S * BK, kbeg, kend);
             }
             if (jb == NBLK - 1) {
@@ -628,7 +656,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
 #pragma unroll
                 for (int j = 0; j < TW; ++j) {
                     const int col = n0 + wn * (BT / 2) + j * 32 + fr;
-                    lg[j][r] = p.ep_logits[(long)rc * p.ep_ld + (col < p.N ? col : 0)];
+                    const long li = (long)rc * p.ep_ld + (col < p.N ? col : 0);
+                    lg[j][r] = p.ep16 ? ld_bf16(p.ep_logits, li) : p.ep_logits[li];
                 }
             }
 #pragma unroll
@@ -640,7 +669,14 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
                     const float pr = __expf(lg[j][r] * inv_tau - lse_r[r]);
                     const float onehot = (tg_r[r] == col) ? 1.f : 0.f;
                     const float v = pr * (acc[0][i][j][r] - rd_r[r]) * inv_tau + ce_scale * (pr - onehot);
-                    if (rv[r] && col < p.N) p.C[(long)row * p.ldc + col] = v;
+                    if (rv[r] && col < p.N) {
+                        if (p.c16) {
+                            st_bf16(p.C, (long)row * p.ldc + col, v);
+                            if (p.ct) st_bf16(p.ct, (long)col * p.ldct + row, v);
+                        } else {
+                            p.C[(long)row * p.ldc + col] = v;
+                        }
+                    }
                 }
             }
         }
@@ -658,6 +694,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
                 if (row >= p.M) continue;
                 if (p.splitk > 1) {
                     p.ws[((long)split * p.M + row) * p.ldw + col] = acc[0][i][j][r];
+                } else if (p.c16) {  // (host: beta == 0; ct only with the softmax-backward epilogue)
+                    const float v = apply_epilogue(p, row, col, acc[0][i][j][r]);
+                    st_bf16(p.C, (long)row * p.ldc + col, v);
+                    if (p.ct) st_bf16(p.ct, (long)col * p.ldct + row, v);
                 } else {
                     p.C[(long)row * p.ldc + col] = apply_epilogue(p, row, col, acc[0][i][j][r]);
                 }
@@ -667,7 +707,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
 }
 
 template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK = (BT == 128 ? 16 : 32), bool SMB = false,
-          bool BF = false, int FK = 0>
+          bool BF = false, int FK = 0, bool A16 = false>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
     // Work item = (K split, tile). Default (order 2): the XCD remap runs over the tile list, m fastest (neighbouring
     // tiles share the B, usually the weight, panel). Orders 0/1 remap over the whole (split, tile) list so that an XCD
@@ -685,7 +725,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
         split = w / ntiles;
         t = w - split * ntiles;
     }
-    gemm_tile<BT, A_KC, B_KC, VEC, EXP, S, BK, SMB, BF, FK>(p, split, t);
+    gemm_tile<BT, A_KC, B_KC, VEC, EXP, S, BK, SMB, BF, FK, A16>(p, split, t);
 }
 
 // Grouped launch: up to GROUP_MAX independent products (same kernel variant) in ONE launch; block b works on the
@@ -824,6 +864,28 @@ void launch_gemm(const GemmParams& p, int bt, bool a_kc, bool b_kc, dim3 grid, h
     }
 }
 
+// bf16-stored A (k-contiguous), bf16 MFMA operands, 16-byte loads on both operands (checked by prepare_gemm)
+template <int BT, bool EXP, int FK>
+void launch_a16_k(const GemmParams& p, bool b_kc, dim3 grid, hipStream_t s) {
+    constexpr int BK = bk_of<BT, true>();
+    if (b_kc)
+        hipLaunchKernelGGL((gemm_kernel<BT, true, true, 3, EXP, 2, BK, false, true, FK, true>), grid, dim3(NT), 0, s, p);
+    else
+        hipLaunchKernelGGL((gemm_kernel<BT, true, false, 3, EXP, 2, BK, false, true, FK, true>), grid, dim3(NT), 0, s, p);
+}
+
+template <int BT>
+void launch_a16_t(const GemmParams& p, bool b_kc, dim3 grid, hipStream_t s) {
+    const bool ex = p.a_transform == CGN_ATRANS_EXP;
+    if (p.fastk == 1) {
+        if (ex) launch_a16_k<BT, true, 1>(p, b_kc, grid, s);
+        else launch_a16_k<BT, false, 1>(p, b_kc, grid, s);
+    } else {
+        if (ex) launch_a16_k<BT, true, 0>(p, b_kc, grid, s);
+        else launch_a16_k<BT, false, 0>(p, b_kc, grid, s);
+    }
+}
+
 template <int VEC, bool BF, int FK>
 void launch_group_vk(const GemmGroup& g, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s) {
     constexpr int BK = bk_of<64, BF>();
@@ -867,6 +929,7 @@ void launch_group(const GemmGroup& g, int vec, bool a_kc, bool b_kc, unsigned bl
 namespace cgn_gemm {
 void launch_gemm_f32ops(const GemmParams& p, int bt, bool a_kc, bool b_kc, dim3 grid, hipStream_t s);
 void launch_gemm_bf16ops(const GemmParams& p, int bt, bool a_kc, bool b_kc, dim3 grid, hipStream_t s);
+void launch_gemm_a16(const GemmParams& p, int bt, bool b_kc, dim3 grid, hipStream_t s);
 void launch_group_f32ops(const GemmGroup& g, int vec, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s);
 void launch_group_bf16ops(const GemmGroup& g, int vec, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s);
 }  // namespace cgn_gemm

@@ -158,7 +158,16 @@ __global__ __launch_bounds__(PW_NT) void reparam_kld_bwd_kernel(const float* __r
 }
 
 // ---- column sums (bias gradients): two fixed-order stages ---------------------------------------------------------
-__global__ __launch_bounds__(PW_NT) void colsum_partial_kernel(const float* __restrict__ x, long ld, int R, int Cn,
+template <bool IN16>
+__device__ __forceinline__ float colsum_at(const void* x, long i) {
+    if constexpr (IN16)
+        return __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(x)[i] << 16);
+    else
+        return reinterpret_cast<const float*>(x)[i];
+}
+// IN16: x holds bf16 (the bf16 mode's dlogits, cgn_gemm_desc.storage)
+template <bool IN16>
+__global__ __launch_bounds__(PW_NT) void colsum_partial_kernel(const void* __restrict__ x, long ld, int R, int Cn,
                                                                int rows_per_chunk, float* __restrict__ part) {
     const int c = blockIdx.x * PW_NT + threadIdx.x;
     if (c >= Cn) return;
@@ -167,12 +176,12 @@ __global__ __launch_bounds__(PW_NT) void colsum_partial_kernel(const float* __re
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int r = r0;
     for (; r + 3 < r1; r += 4) {
-        s0 += x[(long)r * ld + c];
-        s1 += x[(long)(r + 1) * ld + c];
-        s2 += x[(long)(r + 2) * ld + c];
-        s3 += x[(long)(r + 3) * ld + c];
+        s0 += colsum_at<IN16>(x, (long)r * ld + c);
+        s1 += colsum_at<IN16>(x, (long)(r + 1) * ld + c);
+        s2 += colsum_at<IN16>(x, (long)(r + 2) * ld + c);
+        s3 += colsum_at<IN16>(x, (long)(r + 3) * ld + c);
     }
-    for (; r < r1; ++r) s0 += x[(long)r * ld + c];
+    for (; r < r1; ++r) s0 += colsum_at<IN16>(x, (long)r * ld + c);
     part[(long)blockIdx.y * Cn + c] = (s0 + s1) + (s2 + s3);
 }
 __global__ __launch_bounds__(PW_NT) void colsum_final_kernel(const float* __restrict__ part, int nchunk, int Cn,
@@ -522,8 +531,8 @@ extern "C" int cgn_reparam_kld_bwd_f32(void* stream, const float* mulv, const fl
     return CGN_OK;
 }
 
-extern "C" int cgn_colsum_f32(void* stream, const float* x, int64_t ld, int32_t R, int32_t Cn, float beta, float* out,
-                              float* workspace, int64_t workspace_bytes) {
+static int colsum_any(void* stream, const void* x, bool in16, int64_t ld, int32_t R, int32_t Cn, float beta, float* out,
+                      float* workspace, int64_t workspace_bytes) {
     CGN_CHECK_ARG(R >= 0 && Cn > 0);
     CGN_CHECK_ARG(x && out && ld >= Cn && workspace);
     int nchunk = cgn_cdiv(R, 16);  // short row chunks: enough blocks to fill 256 CUs even for narrow matrices
@@ -531,13 +540,27 @@ extern "C" int cgn_colsum_f32(void* stream, const float* x, int64_t ld, int32_t 
     if (nchunk < 1) nchunk = 1;
     if ((long)nchunk * Cn * 4 > workspace_bytes) return CGN_ERR_WORKSPACE;
     const int rpc = cgn_cdiv(R, nchunk);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cgn_cdiv(Cn, PW_NT), nchunk), dim3(PW_NT), 0, S_(stream), x, (long)ld,
-                       R, Cn, rpc, workspace);
+    const dim3 grid(cgn_cdiv(Cn, PW_NT), nchunk);
+    if (in16)
+        hipLaunchKernelGGL(colsum_partial_kernel<true>, grid, dim3(PW_NT), 0, S_(stream), x, (long)ld, R, Cn, rpc, workspace);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<false>, grid, dim3(PW_NT), 0, S_(stream), x, (long)ld, R, Cn, rpc, workspace);
     CGN_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cgn_cdiv(Cn, PW_NT)), dim3(PW_NT), 0, S_(stream), workspace, nchunk, Cn,
                        beta, out);
     CGN_LAUNCH_CHECK();
     return CGN_OK;
+}
+
+extern "C" int cgn_colsum_f32(void* stream, const float* x, int64_t ld, int32_t R, int32_t Cn, float beta, float* out,
+                              float* workspace, int64_t workspace_bytes) {
+    return colsum_any(stream, x, false, ld, R, Cn, beta, out, workspace, workspace_bytes);
+}
+
+extern "C" int cgn_colsum_bf16(void* stream, const void* x, int64_t ld, int32_t R, int32_t Cn, float beta, float* out,
+                               float* workspace, int64_t workspace_bytes) {
+    CGN_CHECK_ARG((uintptr_t)x % 2 == 0);
+    return colsum_any(stream, x, true, ld, R, Cn, beta, out, workspace, workspace_bytes);
 }
 
 extern "C" int cgn_sum_time_f32(void* stream, const float* x, int32_t B, int32_t T, int32_t Cn, float* out) {

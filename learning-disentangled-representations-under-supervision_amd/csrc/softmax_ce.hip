@@ -15,7 +15,25 @@ __device__ __forceinline__ void online_update(float& m, float& s, float x) {
     }
 }
 
-__global__ __launch_bounds__(SM_NT) void softmax_nll_fwd_kernel(const float* __restrict__ logits, long ld,
+typedef unsigned u32x4_sm __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void quad_update(float& m, float& s, float q0, float q1, float q2, float q3) {
+    // one max per quad keeps the expf count at 4 (+1 on a new maximum)
+    const float qm = fmaxf(fmaxf(q0, q1), fmaxf(q2, q3));
+    if (qm > m) {
+        s *= expf(m - qm);
+        m = qm;
+    }
+    s += expf(q0 - m) + expf(q1 - m) + expf(q2 - m) + expf(q3 - m);
+}
+
+__device__ __forceinline__ float bf16_at(const void* base, long i) {
+    return __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(base)[i] << 16);
+}
+
+// IN16: the logits are stored as bf16 (the optional bf16 mode's storage format, cgn_gemm_desc.storage); ld in elements
+template <bool IN16>
+__global__ __launch_bounds__(SM_NT) void softmax_nll_fwd_kernel(const void* __restrict__ logits, long ld,
                                                                 const int64_t* __restrict__ target, int V,
                                                                 float inv_tau_imm, const float* __restrict__ dyn,
                                                                 float* __restrict__ lse, float* __restrict__ nll) {
@@ -23,26 +41,41 @@ __global__ __launch_bounds__(SM_NT) void softmax_nll_fwd_kernel(const float* __r
     __shared__ float red_m[SM_NT / 64];
     __shared__ float red_s[SM_NT / 64];
     const int row = blockIdx.x;
-    const float* x = logits + (long)row * ld;
     float m = -INFINITY, s = 0.f;
-    const bool vec = ((uintptr_t)x % 16 == 0);
-    if (vec) {
-        const int nv = V / 4;
-        const f32x4* xv = reinterpret_cast<const f32x4*>(x);
-        for (int i = threadIdx.x; i < nv; i += SM_NT) {
-            const f32x4 v = xv[i];
-            // one max per quad keeps the expf count at 4 (+1 on a new maximum)
-            const float q0 = v[0] * inv_tau, q1 = v[1] * inv_tau, q2 = v[2] * inv_tau, q3 = v[3] * inv_tau;
-            const float qm = fmaxf(fmaxf(q0, q1), fmaxf(q2, q3));
-            if (qm > m) {
-                s *= expf(m - qm);
-                m = qm;
+    const float* x = IN16 ? nullptr : reinterpret_cast<const float*>(logits) + (long)row * ld;
+    const unsigned short* xh = IN16 ? reinterpret_cast<const unsigned short*>(logits) + (long)row * ld : nullptr;
+    if constexpr (IN16) {
+        if ((uintptr_t)xh % 16 == 0) {
+            const int nv = V / 8;
+            const u32x4_sm* xv = reinterpret_cast<const u32x4_sm*>(xh);
+            for (int i = threadIdx.x; i < nv; i += SM_NT) {
+                const u32x4_sm v = xv[i];
+                float q[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    q[2 * j] = __builtin_bit_cast(float, v[j] << 16) * inv_tau;
+                    q[2 * j + 1] = __builtin_bit_cast(float, v[j] & 0xffff0000u) * inv_tau;
+                }
+                quad_update(m, s, q[0], q[1], q[2], q[3]);
+                quad_update(m, s, q[4], q[5], q[6], q[7]);
             }
-            s += expf(q0 - m) + expf(q1 - m) + expf(q2 - m) + expf(q3 - m);
+            for (int i = nv * 8 + threadIdx.x; i < V; i += SM_NT) online_update(m, s, bf16_at(xh, i) * inv_tau);
+        } else {
+            for (int i = threadIdx.x; i < V; i += SM_NT) online_update(m, s, bf16_at(xh, i) * inv_tau);
         }
-        for (int i = nv * 4 + threadIdx.x; i < V; i += SM_NT) online_update(m, s, x[i] * inv_tau);
     } else {
-        for (int i = threadIdx.x; i < V; i += SM_NT) online_update(m, s, x[i] * inv_tau);
+        const bool vec = ((uintptr_t)x % 16 == 0);
+        if (vec) {
+            const int nv = V / 4;
+            const f32x4* xv = reinterpret_cast<const f32x4*>(x);
+            for (int i = threadIdx.x; i < nv; i += SM_NT) {
+                const f32x4 v = xv[i];
+                quad_update(m, s, v[0] * inv_tau, v[1] * inv_tau, v[2] * inv_tau, v[3] * inv_tau);
+            }
+            for (int i = nv * 4 + threadIdx.x; i < V; i += SM_NT) online_update(m, s, x[i] * inv_tau);
+        } else {
+            for (int i = threadIdx.x; i < V; i += SM_NT) online_update(m, s, x[i] * inv_tau);
+        }
     }
     // wave reduce of (m, s) pairs
 #pragma unroll
@@ -72,7 +105,7 @@ __global__ __launch_bounds__(SM_NT) void softmax_nll_fwd_kernel(const float* __r
         lse[row] = l;
         const int64_t tg = target[row];
         // an out-of-range target yields NaN instead of an out-of-bounds read
-        nll[row] = (tg >= 0 && tg < V) ? l - x[tg] * inv_tau : NAN;
+        nll[row] = (tg >= 0 && tg < V) ? l - (IN16 ? bf16_at(xh, tg) : x[tg]) * inv_tau : NAN;
     }
 }
 
@@ -102,19 +135,35 @@ __global__ void __launch_bounds__(SM_NT) log_softmax_rows_kernel(const float* __
     for (int v = threadIdx.x; v < V; v += SM_NT) dst[v] = src[v] - l;
 }
 
-extern "C" int cgn_softmax_nll_fwd_f32(void* stream, const float* logits, int64_t ld, const int64_t* target, int32_t M,
-                                       int32_t V, float inv_tau, const float* dyn_inv_tau, float* lse, float* nll,
-                                       float* loss) {
+static int softmax_nll_fwd(void* stream, const void* logits, bool in16, int64_t ld, const int64_t* target, int32_t M,
+                           int32_t V, float inv_tau, const float* dyn_inv_tau, float* lse, float* nll, float* loss) {
     CGN_CHECK_ARG(M >= 0 && V > 0 && ld >= V);
     if (M == 0) return CGN_OK;
     CGN_CHECK_ARG(logits && target && lse && nll && loss);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(softmax_nll_fwd_kernel, dim3(M), dim3(SM_NT), 0, s, logits, (long)ld, target, V, inv_tau,
-                       dyn_inv_tau, lse, nll);
+    if (in16)
+        hipLaunchKernelGGL(softmax_nll_fwd_kernel<true>, dim3(M), dim3(SM_NT), 0, s, logits, (long)ld, target, V, inv_tau,
+                           dyn_inv_tau, lse, nll);
+    else
+        hipLaunchKernelGGL(softmax_nll_fwd_kernel<false>, dim3(M), dim3(SM_NT), 0, s, logits, (long)ld, target, V, inv_tau,
+                           dyn_inv_tau, lse, nll);
     CGN_LAUNCH_CHECK();
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, nll, M, 1.0f / (float)M, loss);
     CGN_LAUNCH_CHECK();
     return CGN_OK;
+}
+
+extern "C" int cgn_softmax_nll_fwd_f32(void* stream, const float* logits, int64_t ld, const int64_t* target, int32_t M,
+                                       int32_t V, float inv_tau, const float* dyn_inv_tau, float* lse, float* nll,
+                                       float* loss) {
+    return softmax_nll_fwd(stream, logits, false, ld, target, M, V, inv_tau, dyn_inv_tau, lse, nll, loss);
+}
+
+extern "C" int cgn_softmax_nll_fwd_bf16(void* stream, const void* logits, int64_t ld, const int64_t* target, int32_t M,
+                                        int32_t V, float inv_tau, const float* dyn_inv_tau, float* lse, float* nll,
+                                        float* loss) {
+    CGN_CHECK_ARG((uintptr_t)logits % 2 == 0);
+    return softmax_nll_fwd(stream, logits, true, ld, target, M, V, inv_tau, dyn_inv_tau, lse, nll, loss);
 }
 
 extern "C" int cgn_log_softmax_rows_f32(void* stream, const float* logits, int64_t ld, const float* lse,

@@ -20,6 +20,7 @@ EPI_LINEAR = 0
 EPI_SOFTMAX_BWD = 1
 COMPUTE_F32 = 0
 COMPUTE_BF16 = 1
+STORE_A_BF16, STORE_C_BF16, STORE_EP_BF16 = 1, 2, 4
 
 c_float_p = C.c_void_p  # raw device pointers travel as integers
 c_i64 = C.c_int64
@@ -46,7 +47,8 @@ class GemmDesc(C.Structure):
         ("ep_inv_tau", c_f32), ("ep_ce_scale", c_f32),
         ("force_tile", c_i32), ("force_splitk", c_i32),
         ("dyn_scalars", c_ptr),
-        ("compute", c_i32), ("reserved0", c_i32),
+        ("compute", c_i32), ("storage", c_i32),
+        ("c_t", c_ptr), ("ld_ct", c_i64),
     ]
 
 
@@ -90,6 +92,7 @@ PROTOTYPES = {
     "cgn_gemm_plan": (c_i32, [C.POINTER(GemmDesc), C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32),
                               C.POINTER(c_i32)]),
     "cgn_softmax_nll_fwd_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_i32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "cgn_softmax_nll_fwd_bf16": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_i32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "cgn_log_softmax_rows_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i32, c_i64, c_i32, c_ptr, c_i64]),
     "cgn_lstm_seq_fwd_f32": (c_i32, [c_ptr, C.POINTER(LstmFwdSeq), c_i32, c_i32, c_i32, c_i32]),
     "cgn_lstm_seq_bwd_f32": (c_i32, [c_ptr, C.POINTER(LstmBwdSeq), c_i32, c_i32, c_i32, c_i32]),
@@ -122,6 +125,7 @@ PROTOTYPES = {
     "cgn_reparam_kld_fwd_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr]),
     "cgn_reparam_kld_bwd_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_ptr, c_i32, c_i32, c_ptr]),
     "cgn_colsum_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_i32, c_f32, c_ptr, c_ptr, c_i64]),
+    "cgn_colsum_bf16": (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_i32, c_f32, c_ptr, c_ptr, c_i64]),
     "cgn_sum_time_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr]),
     "cgn_rowdot_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_ptr]),
     "cgn_adam_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_ptr, c_f32]),

@@ -49,6 +49,13 @@ def _chk_f32(t, name):
         raise TypeError("%s must be a float32 CUDA(HIP) tensor" % name)
 
 
+def _chk_f32_or_bf16(t, name):
+    """bf16 STORAGE (the logits-sized tensors of the optional bf16 mode) where the entry point has a bf16 form."""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype in (torch.float32, torch.bfloat16)):
+        raise TypeError("%s must be a float32 or bfloat16 CUDA(HIP) tensor" % name)
+    return t.dtype == torch.bfloat16
+
+
 def _chk_i64(t, name):
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
         raise TypeError("%s must be a contiguous int64 CUDA(HIP) tensor" % name)
@@ -123,7 +130,7 @@ def _span_ok(t, base_off, axes_extents):
 
 def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, bias1=None,
          a_m=None, a_k=None, b_k=None, b_n=None, a_exp=None, softmax_bwd=None, force_tile=0, force_splitk=0,
-         dyn=None, compute=None, _desc_only=False):
+         dyn=None, compute=None, c_t=None, _desc_only=False):
     """out[M,N] = epilogue(alpha * A @ B + beta*out + bias0 + bias1).
 
     `a` is viewed as A[M,K] and `b` as B[K,N]; arbitrary 2-D strides (so `w.t()` is free). The optional cgn Axis
@@ -131,9 +138,13 @@ def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, 
     override is given, M/K/N must be given explicitly and `a`/`b` only provide the base pointer.
     a_exp=(scale, lse): A := exp(A*scale - lse[m]).   softmax_bwd=dict(logits, lse, rowdot, target, inv_tau, ce_scale).
     compute: None (the module-level mode, see set_compute) | 'f32' | 'bf16'.
+    bf16 STORAGE (bf16 compute only, include/cgn_hip.h CGN_STORE_*): `a` may be a bfloat16 [M,K] matrix with unit k stride
+    and rows 16 bytes aligned (K % 8 == 0); `out` and softmax_bwd's logits may be bfloat16; c_t: optional bfloat16 [N, >=M]
+    receiving the transpose of a bfloat16 softmax_bwd result.
     """
     lib = _lib.load()
-    _chk_f32(a, "a"), _chk_f32(b, "b"), _chk_f32(out, "out")
+    a16, c16 = _chk_f32_or_bf16(a, "a"), _chk_f32_or_bf16(out, "out")
+    _chk_f32(b, "b")
     if a_m is None or a_k is None:
         if a.dim() != 2:
             raise ValueError("a must be 2-D unless a_m/a_k are given")
@@ -189,7 +200,8 @@ def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, 
     d.epilogue = _lib.EPI_LINEAR
     if softmax_bwd is not None:
         lg, lse, rd, tg = (softmax_bwd[k] for k in ("logits", "lse", "rowdot", "target"))
-        _chk_f32(lg, "logits"), _chk_f32(lse, "lse"), _chk_f32(rd, "rowdot"), _chk_i64(tg, "target")
+        ep16 = _chk_f32_or_bf16(lg, "logits")
+        _chk_f32(lse, "lse"), _chk_f32(rd, "rowdot"), _chk_i64(tg, "target")
         if lg.dim() != 2 or lg.shape[0] != M or lg.shape[1] != N or lg.stride(1) != 1:
             raise ValueError("softmax_bwd logits must be [M,N]")
         if lse.numel() != M or rd.numel() != M or tg.numel() != M or not (lse.is_contiguous() and rd.is_contiguous()):
@@ -205,6 +217,21 @@ def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, 
     d.force_tile, d.force_splitk = force_tile, force_splitk
     d.dyn_scalars = _ptr(dyn)
     d.compute = COMPUTE if compute is None else (_lib.COMPUTE_BF16 if compute == "bf16" else _lib.COMPUTE_F32)
+    d.storage = ((_lib.STORE_A_BF16 if a16 else 0) | (_lib.STORE_C_BF16 if c16 else 0) |
+                 (_lib.STORE_EP_BF16 if (softmax_bwd is not None and ep16) else 0))
+    if d.storage and d.compute != _lib.COMPUTE_BF16:
+        raise ValueError("bfloat16 tensors need the bf16 compute mode")
+    if a16 and not (a_k.stride == 1 and a_k.rpg == 0 and a_m.rpg == 0 and a_m.stride % 8 == 0 and K % 8 == 0 and K > 0
+                    and a.data_ptr() % 16 == 0):
+        raise ValueError("a bfloat16 A must be [M,K] with unit k stride, K % 8 == 0 and 16-byte aligned rows")
+    if c16 and beta != 0.0:
+        raise ValueError("a bfloat16 out cannot be accumulated into (beta must be 0)")
+    if c_t is not None:
+        if not (c16 and softmax_bwd is not None and isinstance(c_t, torch.Tensor) and c_t.is_cuda
+                and c_t.dtype == torch.bfloat16 and c_t.dim() == 2 and c_t.shape[0] == N and c_t.shape[1] == M
+                and c_t.stride(1) == 1 and c_t.device == dev):
+            raise ValueError("c_t must be a bfloat16 [N,M] matrix beside a bfloat16 softmax_bwd result")
+        d.c_t, d.ld_ct = _ptr(c_t), c_t.stride(0)
     if _desc_only:
         return d
     prof = GEMM_PROFILE
@@ -282,17 +309,18 @@ def softmax_nll_fwd(logits, target, inv_tau, dyn=None):
     """Returns (lse[M], nll[M], loss[1]) for logits [M,V] (row stride free), model/cgn.py:1086-1092.
     dyn: optional device float tensor whose element 0 overrides inv_tau at run time (graph replay)."""
     lib = _lib.load()
-    _chk_f32(logits, "logits"), _chk_i64(target, "target")
+    in16 = _chk_f32_or_bf16(logits, "logits")
+    _chk_i64(target, "target")
     if logits.dim() != 2 or logits.stride(1) != 1:
         raise ValueError("logits must be [M,V] with unit column stride")
     M, V = logits.shape
     if target.numel() != M:
         raise ValueError("target must have M elements")
     lse, nll, loss = alloc((M,), logits.device), alloc((M,), logits.device), alloc((1,), logits.device)
+    name = "cgn_softmax_nll_fwd_bf16" if in16 else "cgn_softmax_nll_fwd_f32"
     with torch.cuda.device(logits.device):
-        _lib.check(lib.cgn_softmax_nll_fwd_f32(_stream(), _ptr(logits), logits.stride(0), _ptr(target), M, V,
-                                               inv_tau, _ptr(dyn), _ptr(lse), _ptr(nll), _ptr(loss)),
-                   "cgn_softmax_nll_fwd_f32")
+        _lib.check(getattr(lib, name)(_stream(), _ptr(logits), logits.stride(0), _ptr(target), M, V,
+                                      inv_tau, _ptr(dyn), _ptr(lse), _ptr(nll), _ptr(loss)), name)
     return lse, nll, loss
 
 
@@ -433,6 +461,14 @@ def reparam_kld_bwd(mulv, eps, g, kld_weight, dmulv, dyn=None):
 
 
 def colsum(x, out, beta=0.0):
+    if isinstance(x, torch.Tensor) and x.dtype == torch.bfloat16:  # the bf16 mode's dlogits (bf16 storage)
+        _req(x.is_cuda and x.dim() == 2 and x.stride(1) == 1, "colsum x must be [R,C] with unit column stride")
+        _chk_f32(out, "out")
+        R, Cn = x.shape
+        _req(out.is_contiguous() and out.numel() == Cn, "colsum out must have C elements")
+        ws = workspace(x.device)
+        _call("cgn_colsum_bf16", x.device, _ptr(x), x.stride(0), R, Cn, beta, _ptr(out), _ptr(ws), ws.numel() * 4)
+        return out
     ld = _rows2d(x, "x")
     _chk_f32(out, "out")
     R, Cn = x.shape

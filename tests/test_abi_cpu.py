@@ -46,7 +46,7 @@ def test_library_loads_and_exports_every_symbol():
     lib = _lib.load()
     for name in _declarations():
         assert hasattr(lib, name), "libcgn_hip.so does not export %s" % name
-    assert lib.cgn_abi_version() == 3
+    assert lib.cgn_abi_version() == 4
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -265,3 +265,123 @@ def test_gemm_bf16_splitk_windows_group_and_softmax(dev):
     ops.gemm(dod, embd.t(), dlogits, compute="bf16",
              softmax_bwd=dict(logits=lg, lse=lse, rowdot=rowdot, target=tg, inv_tau=1.0 / tau, ce_scale=79.0 / (M * tau)))
     assert _rel(dlogits, logits.grad) < 1e-2
+
+
+# ---- bf16 STORAGE of the logits-sized tensors (cgn_gemm_desc.storage, CGN_STORE_*) ---------------------------------
+@pytest.mark.parametrize("M,N,K", [(200, 300, 96), (65, 129, 824), (1, 8, 8), (1344, 512, 2000), (300, 64, 4096)])
+@pytest.mark.parametrize("b_layout", ["n", "t"])
+@pytest.mark.parametrize("tile", [0, 64, 128])
+def test_gemm_bf16_stored_a(dev, M, N, K, b_layout, tile):
+    """A held as bfloat16 in memory (read with 16-byte loads straight into the bf16 LDS image), B fp32 rounded inside the
+    kernel: equal to the fp64 product of the bf16 values up to fp32 summation order; exact on small integers."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 131 + N * 17 + K)
+    ints = (M + N + K) % 2 == 0
+    A = _mk((M, K), g, ints)
+    B = _mk((K, N), g, ints)
+    a = A.to(dev).to(torch.bfloat16)
+    ref = a.cpu().double() @ _bf(B).double()
+    b = B.to(dev) if b_layout == "n" else B.t().contiguous().to(dev).t()
+    if N % 4:  # (16-byte loads along n need aligned rows: the library rejects a B it cannot read that way)
+        b = b if b_layout == "t" and K % 4 == 0 else None
+    if b is None:
+        pytest.skip("B not readable with 16-byte loads")
+    out = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(a, b, out, force_tile=tile, compute="bf16")
+    if ints:
+        assert torch.equal(out.cpu().double(), ref)
+    else:
+        assert _rel(out, ref) < 2e-6
+
+
+def test_gemm_bf16_stored_a_rows_with_padding_and_split_k(dev):
+    """Row stride larger than K (a view into a wider bf16 matrix) and a forced K split."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    M, N, K, ld = 150, 96, 1600, 1608
+    big = torch.randn(M, ld, generator=g).to(dev).to(torch.bfloat16)
+    a = big[:, :K]
+    B = torch.randn(K, N, generator=g)
+    ref = a.cpu().double() @ _bf(B).double()
+    for sk in (0, 5):
+        out = torch.full((M, N), float("nan"), device=dev)
+        ops.gemm(a, B.to(dev), out, compute="bf16", force_splitk=sk)
+        assert _rel(out, ref) < 2e-6, sk
+
+
+def test_gemm_bf16_storage_rejects_what_it_cannot_read(dev):
+    ops = _ops()
+    a = torch.zeros(16, 24, device=dev, dtype=torch.bfloat16)
+    b = torch.zeros(24, 16, device=dev)
+    out = torch.zeros(16, 16, device=dev)
+    with pytest.raises(ValueError):
+        ops.gemm(a, b, out, compute="f32")  # bf16 tensors need the bf16 mode
+    with pytest.raises(ValueError):
+        ops.gemm(a[:, :20], b[:20], out, compute="bf16")  # K % 8
+    with pytest.raises(ValueError):
+        ops.gemm(a.t().contiguous().t(), b, out, compute="bf16")  # not k-contiguous
+    with pytest.raises(ValueError):
+        ops.gemm(a, b, out.to(torch.bfloat16), beta=1.0, compute="bf16")
+
+
+@pytest.mark.parametrize("M,V,E", [(96, 1200, 300), (130, 2056, 64)])
+def test_gemm_bf16_stored_logits_chain(dev, M, V, E):
+    """The generator's output layer with the logits-sized tensors held in bfloat16, product by product:
+    vocabulary projection -> bf16 logits; softmax/NLL over bf16 logits; soft embedding with the exp loader over bf16
+    logits; fused softmax backward reading bf16 logits in place, writing bf16 dlogits AND their transpose; dH and dW from
+    the bf16 dlogits; bias gradient. Every step against fp64 math on the SAME bf16 inputs (so only the kernel's own
+    rounding is measured): fp32 outputs 2e-5 (exp operand: 1e-2 bar of the mode, measured ~2e-3), bf16 outputs within
+    one bf16 ulp (2^-8 relative) of the fp64 value."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + V)
+    H, tau = 64, 0.7
+    h = torch.randn(M, H, generator=g)
+    W = torch.randn(V, H, generator=g) * 0.2
+    bias = torch.randn(V, generator=g) * 0.1
+    tgt = torch.randint(0, V, (M,), generator=g)
+    emb = torch.randn(V, E, generator=g) * 0.5
+    dout = torch.randn(M, E, generator=g)
+    hd, Wd, embd, tgd = h.to(dev), W.to(dev), emb.to(dev), tgt.to(dev)
+    # 1. logits = h W^T + b, stored bf16
+    logits = torch.full((M, V), float("nan"), device=dev, dtype=torch.bfloat16)
+    ops.gemm(hd, Wd.t(), logits, bias0=bias.to(dev), compute="bf16")
+    ref_logits = _bf(h).double() @ _bf(W).double().t() + bias.double()
+    got = logits.float().cpu().double()
+    assert ((got - ref_logits).abs() <= ref_logits.abs() * 2.0 ** -8 + 1e-6).all()
+    L = got  # everything downstream is checked against THESE stored values
+    # 2. softmax / NLL
+    lse, nll, loss = ops.softmax_nll_fwd(logits, tgd, 1.0 / tau)
+    ref_lse = torch.logsumexp(L / tau, 1)
+    assert (lse.cpu().double() - ref_lse).abs().max().item() < 1e-4
+    assert (nll.cpu().double() - (ref_lse - L[torch.arange(M), tgt] / tau)).abs().max().item() < 1e-4
+    # 3. soft embedding: softmax(L/tau) @ E with the probabilities formed in the loader from the bf16 logits
+    out_emb = torch.full((M, E), float("nan"), device=dev)
+    ops.gemm(logits, embd, out_emb, a_exp=(1.0 / tau, lse), compute="bf16")
+    P = torch.exp(L / tau - ref_lse[:, None])
+    assert _rel(out_emb, P @ emb.double()) < 1e-2
+    # 4. fused softmax/CE backward in place over the bf16 logits, plus the transposed copy
+    rowdot = torch.empty(M, device=dev)
+    ops.rowdot(dout.to(dev), out_emb, rowdot)
+    ce_scale = 79.0 / tau / M
+    dlt = torch.full((V, M), float("nan"), device=dev, dtype=torch.bfloat16)
+    ops.gemm(dout.to(dev), embd.t(), logits, compute="bf16", c_t=dlt,
+             softmax_bwd=dict(logits=logits, lse=lse, rowdot=rowdot, target=tgd, inv_tau=1.0 / tau, ce_scale=ce_scale))
+    acc = dout.double() @ emb.double().t()
+    onehot = torch.zeros(M, V, dtype=torch.float64)
+    onehot[torch.arange(M), tgt] = 1.0
+    ref_dl = P * (acc - rowdot.cpu().double()[:, None]) / tau + ce_scale * (P - onehot)
+    dl = logits.float().cpu().double()
+    assert _rel(dl, ref_dl) < 1e-2  # (bf16 operands of the product itself: the mode's bar)
+    assert torch.equal(dlt.float().cpu(), logits.float().cpu().t())
+    # 5. dH = dlogits @ W (A bf16, K = V) and dW = dlogits^T @ h (A = the transposed copy, K = M)
+    if M % 8 == 0:
+        dH = torch.full((M, H), float("nan"), device=dev)
+        ops.gemm(logits, Wd, dH, compute="bf16")
+        assert _rel(dH, dl @ _bf(W).double()) < 2e-5
+        dW = torch.full((V, H), float("nan"), device=dev)
+        ops.gemm(dlt, hd, dW, compute="bf16")
+        assert _rel(dW, dl.t() @ _bf(h).double()) < 2e-5
+    # 6. bias gradient
+    db = torch.empty(V, device=dev)
+    ops.colsum(logits, db)
+    assert _rel(db, dl.sum(0)) < 2e-6
