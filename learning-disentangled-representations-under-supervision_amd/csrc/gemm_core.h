@@ -663,18 +663,61 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
 #pragma unroll
             for (int j = 0; j < TW; ++j) {
                 const int col = n0 + wn * (BT / 2) + j * 32 + fr;
+                float v[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * (BT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
                     const float pr = __expf(lg[j][r] * inv_tau - lse_r[r]);
                     const float onehot = (tg_r[r] == col) ? 1.f : 0.f;
-                    const float v = pr * (acc[0][i][j][r] - rd_r[r]) * inv_tau + ce_scale * (pr - onehot);
-                    if (rv[r] && col < p.N) {
-                        if (p.c16) {
-                            st_bf16(p.C, (long)row * p.ldc + col, v);
-                            if (p.ct) st_bf16(p.ct, (long)col * p.ldct + row, v);
+                    v[r] = pr * (acc[0][i][j][r] - rd_r[r]) * inv_tau + ce_scale * (pr - onehot);
+                }
+                if (!p.c16) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wm * (BT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                        if (rv[r] && col < p.N) p.C[(long)row * p.ldc + col] = v[r];
+                    }
+                    continue;
+                }
+                // bf16 C: neighbouring lanes hold neighbouring columns; the even lane of a pair stores both columns of
+                // row r, the odd lane both of row r+1 (one 4-byte store each instead of two 2-byte stores each)
+                const bool pair_ok = (p.ldc % 2 == 0) && ((uintptr_t)p.C % 4 == 0) && (n0 % 2 == 0);
+                const int odd = lane & 1;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float give = odd ? v[r] : v[r + 1];
+                    const float got = __shfl_xor(give, 1, 64);
+                    const int rr = r + odd;
+                    const int row = m0 + wm * (BT / 2) + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * fk;
+                    const int c0 = col - odd;  // even column of the pair
+                    const bool rok = odd ? rv[r + 1] : rv[r];
+                    if (pair_ok && c0 + 1 < p.N) {
+                        if (rok)
+                            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(p.C) + (long)row * p.ldc + c0) =
+                                odd ? pack_bf16x2(got, v[r + 1]) : pack_bf16x2(v[r], got);
+                    } else {  // ragged edge / unaligned rows: every lane stores its own two elements
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int ru = r + u;
+                            const int rowu = m0 + wm * (BT / 2) + i * 32 + (ru & 3) + 8 * (ru >> 2) + 4 * fk;
+                            if (rv[ru] && col < p.N) st_bf16(p.C, (long)rowu * p.ldc + col, v[ru]);
+                        }
+                    }
+                }
+                if (p.ct && col < p.N) {
+                    // transposed copy: a lane's four consecutive rows of one column are 8 contiguous bytes of ct
+                    const bool quad_ok = (p.ldct % 4 == 0) && ((uintptr_t)p.ct % 8 == 0);
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const int row0 = m0 + wm * (BT / 2) + i * 32 + 8 * rq + 4 * fk;
+                        if (quad_ok && row0 + 3 < p.M) {
+                            u32x2 w;
+                            w[0] = pack_bf16x2(v[4 * rq], v[4 * rq + 1]);
+                            w[1] = pack_bf16x2(v[4 * rq + 2], v[4 * rq + 3]);
+                            *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.ct) + (long)col * p.ldct + row0) = w;
                         } else {
-                            p.C[(long)row * p.ldc + col] = v;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (row0 + u < p.M) st_bf16(p.ct, (long)col * p.ldct + row0 + u, v[4 * rq + u]);
                         }
                     }
                 }

@@ -22,6 +22,11 @@ WORKSPACE_BYTES = 96 << 20
 COMPUTE = _lib.COMPUTE_BF16 if os.environ.get("CGN_COMPUTE", "f32").lower() == "bf16" else _lib.COMPUTE_F32
 
 
+# bf16 mode only: hold the logits-sized tensors of the generator's output layer in bf16 (hip/step.py; CGN_STORE_* in
+# include/cgn_hip.h). CGN_BF16_STORAGE=0 keeps every tensor fp32 (operands are then rounded inside the kernels only).
+BF16_STORAGE = os.environ.get("CGN_BF16_STORAGE", "1") != "0"
+
+
 def set_compute(mode):
     """'f32' | 'bf16'; returns the previous mode."""
     global COMPUTE

@@ -566,7 +566,11 @@ class CGNStep:
                      bias0=P["generator.rnn.bias_ih_l1"], bias1=P["generator.rnn.bias_hh_l1"])
             engine.lstm_run_fwd([g1], [P["generator.rnn.weight_hh_l1"]])
         h1, h1ax = g1.hout_operand()
-        logits = _new((NT, V), dev)
+        # bf16 mode: the logits-sized tensors (logits, dlogits and the transposed copy dW_fc reads) are HELD in bf16 when the
+        # shapes allow 16-byte rows (ops.BF16_STORAGE; include/cgn_hip.h CGN_STORE_*): half the HBM bytes of the five
+        # largest products' big operand. Everything else stays fp32.
+        store16 = ops.get_compute() == "bf16" and ops.BF16_STORAGE and V % 8 == 0 and NT % 8 == 0
+        logits = _new((NT, V), dev, torch.bfloat16 if store16 else torch.float32)
         ops.gemm(h1, P["generator.fc.weight"].t(), logits, M=NT, K=Hg, a_m=h1ax, a_k=LIN, bias0=P["generator.fc.bias"])
         # ---- temperature softmax + CE (cgn.py:1086-1092) -------------------------------------------------------
         tgt = target.reshape(-1)
@@ -626,9 +630,10 @@ class CGNStep:
             return ce, kld, z_loss, c_loss, enc_loss, gen_loss
         # ---- backward through softmax/CE + soft embedding, fused, in place over the logits ----------------------
         rowdot = _new((NT,), dev)
+        dlogits_t = _new((V, NT), dev, torch.bfloat16) if store16 else None  # k-contiguous A operand of dW_fc
         if need_soft:
             ops.rowdot(d_out_emb, out_emb, rowdot)
-            ops.gemm(d_out_emb, table.t(), logits,
+            ops.gemm(d_out_emb, table.t(), logits, c_t=dlogits_t,
                      softmax_bwd=dict(logits=logits, lse=lse, rowdot=rowdot, target=tgt, inv_tau=inv_tau,
                                       ce_scale=79.0 * inv_tau / NT), dyn=self._dyn())
         else:
@@ -636,7 +641,7 @@ class CGNStep:
             ops.fill(rowdot, 0.0)
             # (explicit K = 0 over real operands: torch hands out a NULL data_ptr for zero-element views)
             ops.gemm(rowdot, table, logits, M=NT, N=V, K=0, a_m=Axis(1, 0, 0), a_k=LIN,
-                     b_k=LIN, b_n=Axis(table.stride(0), 0, 0),
+                     b_k=LIN, b_n=Axis(table.stride(0), 0, 0), c_t=dlogits_t,
                      softmax_bwd=dict(logits=logits, lse=lse, rowdot=rowdot, target=tgt, inv_tau=inv_tau,
                                       ce_scale=79.0 * inv_tau / NT), dyn=self._dyn())
         dlogits = logits
@@ -646,7 +651,8 @@ class CGNStep:
         # queued (later) and forked behind the encoder's LSTM backward, the step's last persistent launch (see
         # exclusive()); otherwise they run here.
         self.begin_defer(capture)
-        self.later(1, lambda: (ops.gemm(dlogits.t(), h1, G["generator.fc.weight"], N=Hg, K=NT, b_k=h1ax, b_n=LIN),
+        dl_rows = dlogits_t if store16 else dlogits.t()  # A[v, (b,t)] of dW_fc = dlogits^T . h1
+        self.later(1, lambda: (ops.gemm(dl_rows, h1, G["generator.fc.weight"], N=Hg, K=NT, b_k=h1ax, b_n=LIN),
                                ops.colsum(dlogits, G["generator.fc.bias"])))
         # ---- generator LSTM backward ---------------------------------------------------------------------------
         self.exclusive()

@@ -139,6 +139,44 @@ def test_wake_sleep_step_bf16_mode(dev, name, B, calc_z):
         ops.set_compute(prev)
 
 
+@pytest.mark.parametrize("name,B,calc_z", [("mid", 16, False), ("cfg2", 64, False)])
+def test_wake_sleep_step_bf16_mode_with_fp32_storage(dev, name, B, calc_z, monkeypatch):
+    """The bf16 mode with CGN_BF16_STORAGE=0: operands rounded inside the kernels only, every tensor fp32 in memory (the
+    default of the mode holds the logits-sized tensors in bf16: test_wake_sleep_step_bf16_mode)."""
+    from ldrs_amd.hip import ops
+    monkeypatch.setattr(ops, "BF16_STORAGE", False)
+    prev = ops.set_compute("bf16")
+    try:
+        _step_parity(dev, name, B, calc_z, 1e-2)
+    finally:
+        ops.set_compute(prev)
+
+
+def test_bf16_mode_holds_the_logits_sized_tensors_in_bf16(dev, monkeypatch):
+    """bf16 storage is what runs in the bf16 mode when the shapes allow it: the step allocates [B*T, V] and [V, B*T]
+    bfloat16 tensors and no fp32 tensor of that size."""
+    import torch
+    from ldrs_amd.hip import ops
+    V = CFGS["mid"]["word_vocab_size"]
+    seen = []
+    real = ops.alloc
+
+    def spy(shape, dev_, dtype=torch.float32):
+        seen.append((tuple(shape) if not isinstance(shape, int) else (shape,), dtype))
+        return real(shape, dev_, dtype)
+
+    monkeypatch.setattr(ops, "alloc", spy)
+    prev = ops.set_compute("bf16")
+    try:
+        _step_parity(dev, "mid", 16, False, 1e-2)
+    finally:
+        ops.set_compute(prev)
+    big = [(sh, dt) for sh, dt in seen if len(sh) == 2 and V in sh and min(sh) >= 16 * 8]
+    assert any(dt == torch.bfloat16 and sh[1] == V for sh, dt in big), big
+    assert any(dt == torch.bfloat16 and sh[0] == V for sh, dt in big), big
+    assert not any(dt == torch.float32 and sh[1] == V and sh[0] > 64 for sh, dt in big), big
+
+
 class Report:
     """Every comparison of one parity case: (kind, tensor, step, measured relative error, bar). Nothing is asserted
     until the case is over, so a failing case still lists every error; with CGN_PARITY_REPORT=<dir> the table is also
