@@ -262,10 +262,11 @@ def main():
             "config": {"workload": "CGN full wake-sleep training step (disc step + c inference + enc/gen step + 3 Adam), "
                                    + ("BASELINE configs[1]: vocab 20k, seq len 20, batch 64/GPU, emb 300, hidden 512, "
                                       "z 64, " if args.workload == "cfg2" else
-                                      "BASELINE configs[3] SHAPES (stress, not the metric's workload; fp32 tensors): vocab 50k, "
+                                      "BASELINE configs[3] SHAPES (stress, not the metric's workload): vocab 50k, "
                                       "seq len 40, batch 256/GPU, hidden 1024, z 64, ")
                                    + ("fp32" if args.compute == "f32" else "OPTIONAL bf16 mode (bf16 MFMA operands, fp32 "
-                                      "accumulation and storage; not the metric's fp32 configuration)")
+                                      "accumulation; logits / dlogits %s; everything else fp32 in memory; not the "
+                                      "metric's fp32 configuration)" % ("held in bf16" if ops.BF16_STORAGE else "fp32"))
                                    + ", calc_z_loss=%s" % args.z_loss,
                        "global_batch": world * BATCH, "seq_len": SEQ, "parallelism": "dp%d" % world,
                        "launch": launch},

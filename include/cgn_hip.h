@@ -32,7 +32,8 @@ extern "C" {
 int cgn_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
- * GEMM (fp32 in memory, fp32 accumulate; fp32 or, optionally, bf16 MFMA operands): C = epilogue(alpha * A·B [+ beta*C] [+ bias]).
+ * GEMM (fp32 in memory unless `storage` says otherwise, fp32 accumulate; fp32 or, optionally, bf16 MFMA operands):
+ *   C = epilogue(alpha * A·B [+ beta*C] [+ bias]).
  * Replaces every nn.Linear / t.mm / LSTM input projection / Conv2d-as-GEMM call site on the path:
  *   selfModules/highway.py:39-42, model/encoder.py:17-21 (W_ih), model/generator.py:17-22,61 (W_ih, fc),
  *   model/cgn.py:91-92 (e2mu/e2logvar), model/cgn.py:1106 (softmax @ E), model/discriminator_sentiment.py:64
@@ -98,7 +99,7 @@ typedef struct cgn_gemm_desc {
     /* Operand type of the product (the optional bf16 mode): CGN_COMPUTE_F32 = exact fp32 (v_mfma_f32_32x32x2_f32);
      * CGN_COMPUTE_BF16 = A (after a_transform) and B are rounded to bf16 (nearest-even) as they are staged into LDS
      * and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation. Memory operands, bias, epilogue, split-K
-     * slabs and C stay fp32 in both modes. */
+     * slabs and C stay fp32 in both modes unless `storage` names a tensor. */
     int32_t compute;
     int32_t storage; /* CGN_STORE_* bits, 0 = every tensor fp32 */
     /* CGN_EPI_SOFTMAX_BWD with CGN_STORE_C_BF16 only, nullable: a transposed bf16 copy of C, c_t[n * ld_ct + m] — the
