@@ -216,7 +216,9 @@ class Report:
 
 def _step_parity(dev, name, B, calc_z, TOL):
     bf16 = TOL > 1e-3
-    rep = Report("%s_B%d_%s%s" % (name, B, "z" if calc_z else "noz", "_bf16" if bf16 else ""))
+    from ldrs_amd.hip import ops as _ops
+    rep = Report("%s_B%d_%s%s" % (name, B, "z" if calc_z else "noz",
+                                  ("_bf16" if _ops.BF16_STORAGE else "_bf16_fp32storage") if bf16 else ""))
     ocfg, oracle, cfg, model = build(name, dev)
     L = ocfg.max_seq_len - 1
     F_ = len(ocfg.sentiment_kernel_size) * ocfg.sentiment_kernel_num
