@@ -638,8 +638,16 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
         // Fused softmax/CE backward (dlogits written over the logits): per 32-row slab the per-row operands (lse,
         // rowdot, target) are loaded once and ALL logits of the slab are requested (clamped addresses, no branch)
         // before the first exp, instead of four dependent loads per output element.
+        // bf16 C (cgn_gemm_desc.storage): the wave's 64x64 sub-tile is staged through LDS (free after the K loop) and
+        // leaves as 16-byte row stores; the optional transposed copy ct is staged the same way from the packed values.
+        static_assert(BT == 128, "the staged bf16 epilogue is laid out for the 128-tile (4 waves x 64x64)");
+        constexpr int RS = 72;  // staging row stride in bf16 elements (144 B: 16-byte aligned rows)
+        static_assert(4 * 64 * RS * 2 <= 4 * TILE * 4, "staging images must fit the operand buffers");
+        unsigned short* stage = reinterpret_cast<unsigned short*>(lds) + wave * (64 * RS);
         const float inv_tau = p.dyn ? p.dyn[0] : p.ep_inv_tau;
         const float ce_scale = p.dyn ? p.dyn[1] : p.ep_ce_scale;
+        u32x2 pk[TW][TW][4];  // bf16 C only: the lane's values, four consecutive rows of one column per entry
+        if (p.c16) __syncthreads();  // (uniform) every wave is done with the operand images
 #pragma unroll
         for (int i = 0; i < TW; ++i) {
             float lse_r[16], rd_r[16], lg[TW][16];
@@ -653,11 +661,36 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
                 lse_r[r] = p.ep_lse[rc];
                 rd_r[r] = p.ep_rowdot[rc];
                 tg_r[r] = (int)p.ep_target[rc];
+            }
+            // (ONE uniform branch around the whole batch of loads: a select per element would put a branch between the
+            // loads and serialise their round trips, see TileLoader::load)
+            if (p.ep16) {
+                const unsigned short* lgp = reinterpret_cast<const unsigned short*>(p.ep_logits);
+                unsigned short raw[TW][16];
 #pragma unroll
-                for (int j = 0; j < TW; ++j) {
-                    const int col = n0 + wn * (BT / 2) + j * 32 + fr;
-                    const long li = (long)rc * p.ep_ld + (col < p.N ? col : 0);
-                    lg[j][r] = p.ep16 ? ld_bf16(p.ep_logits, li) : p.ep_logits[li];
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * (BT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    const long ro = (long)(rv[r] ? row : 0) * p.ep_ld;
+#pragma unroll
+                    for (int j = 0; j < TW; ++j) {
+                        const int col = n0 + wn * (BT / 2) + j * 32 + fr;
+                        raw[j][r] = lgp[ro + (col < p.N ? col : 0)];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int j = 0; j < TW; ++j) lg[j][r] = __builtin_bit_cast(float, (unsigned)raw[j][r] << 16);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * (BT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    const long ro = (long)(rv[r] ? row : 0) * p.ep_ld;
+#pragma unroll
+                    for (int j = 0; j < TW; ++j) {
+                        const int col = n0 + wn * (BT / 2) + j * 32 + fr;
+                        lg[j][r] = p.ep_logits[ro + (col < p.N ? col : 0)];
+                    }
                 }
             }
 #pragma unroll
@@ -678,48 +711,76 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
                     }
                     continue;
                 }
-                // bf16 C: neighbouring lanes hold neighbouring columns; the even lane of a pair stores both columns of
-                // row r, the odd lane both of row r+1 (one 4-byte store each instead of two 2-byte stores each)
-                const bool pair_ok = (p.ldc % 2 == 0) && ((uintptr_t)p.C % 4 == 0) && (n0 % 2 == 0);
-                const int odd = lane & 1;
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const float give = odd ? v[r] : v[r + 1];
-                    const float got = __shfl_xor(give, 1, 64);
-                    const int rr = r + odd;
-                    const int row = m0 + wm * (BT / 2) + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * fk;
-                    const int c0 = col - odd;  // even column of the pair
-                    const bool rok = odd ? rv[r + 1] : rv[r];
-                    if (pair_ok && c0 + 1 < p.N) {
-                        if (rok)
-                            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(p.C) + (long)row * p.ldc + c0) =
-                                odd ? pack_bf16x2(got, v[r + 1]) : pack_bf16x2(v[r], got);
-                    } else {  // ragged edge / unaligned rows: every lane stores its own two elements
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const int ru = r + u;
-                            const int rowu = m0 + wm * (BT / 2) + i * 32 + (ru & 3) + 8 * (ru >> 2) + 4 * fk;
-                            if (rv[ru] && col < p.N) st_bf16(p.C, (long)rowu * p.ldc + col, v[ru]);
-                        }
-                    }
+                for (int rq = 0; rq < 4; ++rq) {
+                    pk[i][j][rq][0] = pack_bf16x2(v[4 * rq], v[4 * rq + 1]);
+                    pk[i][j][rq][1] = pack_bf16x2(v[4 * rq + 2], v[4 * rq + 3]);
                 }
-                if (p.ct && col < p.N) {
-                    // transposed copy: a lane's four consecutive rows of one column are 8 contiguous bytes of ct
-                    const bool quad_ok = (p.ldct % 4 == 0) && ((uintptr_t)p.ct % 8 == 0);
+                // row-major image: lanes along the columns (2-byte writes, conflict-free)
 #pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) {
-                        const int row0 = m0 + wm * (BT / 2) + i * 32 + 8 * rq + 4 * fk;
-                        if (quad_ok && row0 + 3 < p.M) {
-                            u32x2 w;
-                            w[0] = pack_bf16x2(v[4 * rq], v[4 * rq + 1]);
-                            w[1] = pack_bf16x2(v[4 * rq + 2], v[4 * rq + 3]);
-                            *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.ct) + (long)col * p.ldct + row0) = w;
-                        } else {
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    const unsigned w = pk[i][j][r >> 2][(r & 3) >> 1];
+                    stage[rl * RS + j * 32 + fr] = (unsigned short)((r & 1) ? (w >> 16) : (w & 0xffffu));
+                }
+            }
+        }
+        if (!p.c16) return;
+        // (all of this wave's logits were read above: the in-place stores below cannot run ahead of a read)
+        const int sub_m = m0 + wm * (BT / 2), sub_n = n0 + wn * (BT / 2);
+        auto flush = [&](void* dst, long ld, int row_base, int row_lim, int col_base, int col_lim) {
+            // the staged 64x64 image -> dst[(row_base + r) * ld + col_base + c]: a lane moves 8 consecutive columns of
+            // one row (16 bytes), 8 lanes per row, 8 rows per pass
+            const bool vec_ok = (ld % 8 == 0) && ((uintptr_t)dst % 16 == 0) && (col_base % 8 == 0);
 #pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                if (row0 + u < p.M) st_bf16(p.ct, (long)col * p.ldct + row0 + u, v[4 * rq + u]);
-                        }
-                    }
+            for (int it = 0; it < 8; ++it) {
+                const int rl = it * 8 + (lane >> 3), cl = (lane & 7) * 8;
+                const int row = row_base + rl, col = col_base + cl;
+                const u32x4_t q = *reinterpret_cast<const u32x4_t*>(stage + rl * RS + cl);
+                if (row >= row_lim || col >= col_lim) continue;
+                unsigned short* out = reinterpret_cast<unsigned short*>(dst) + (long)row * ld + col;
+                if (vec_ok && col + 7 < col_lim) {
+                    *reinterpret_cast<u32x4_t*>(out) = q;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (col + e < col_lim) out[e] = (unsigned short)((e & 1) ? (q[e >> 1] >> 16) : (q[e >> 1] & 0xffffu));
+                }
+            }
+        };
+        __syncthreads();
+        flush(p.C, p.ldc, sub_m, p.M, sub_n, p.N);
+        if (p.ct) {
+            __syncthreads();  // (uniform) the row-major image has been read
+            // transposed image: stage[column][row], a lane's four consecutive rows of one column are one 8-byte write
+#pragma unroll
+            for (int i = 0; i < TW; ++i)
+#pragma unroll
+                for (int j = 0; j < TW; ++j)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq)
+                        *reinterpret_cast<u32x2*>(stage + (j * 32 + fr) * RS + i * 32 + 8 * rq + 4 * fk) = pk[i][j][rq];
+            __syncthreads();
+            flush(p.ct, p.ldct, sub_n, p.N, sub_m, p.M);
+        }
+        return;
+    }
+    if (p.c16) {
+        // bf16 C (cgn_gemm_desc.storage; host: no split-K, beta == 0). Its own loop nest: a c16 test inside the fp32
+        // store loop below cost the fp32 products 13-25 % (the stores no longer issued back to back).
+#pragma unroll
+        for (int i = 0; i < TW; ++i) {
+#pragma unroll
+            for (int j = 0; j < TW; ++j) {
+                const int col = n0 + wn * (BT / 2) + j * 32 + fr;
+                if (col >= p.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * (BT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    if (row >= p.M) continue;
+                    const float v = apply_epilogue(p, row, col, acc[0][i][j][r]);
+                    st_bf16(p.C, (long)row * p.ldc + col, v);
+                    if (p.ct) st_bf16(p.ct, (long)col * p.ldct + row, v);
                 }
             }
         }
@@ -737,10 +798,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
                 if (row >= p.M) continue;
                 if (p.splitk > 1) {
                     p.ws[((long)split * p.M + row) * p.ldw + col] = acc[0][i][j][r];
-                } else if (p.c16) {  // (host: beta == 0; ct only with the softmax-backward epilogue)
-                    const float v = apply_epilogue(p, row, col, acc[0][i][j][r]);
-                    st_bf16(p.C, (long)row * p.ldc + col, v);
-                    if (p.ct) st_bf16(p.ct, (long)col * p.ldct + row, v);
                 } else {
                     p.C[(long)row * p.ldc + col] = apply_epilogue(p, row, col, acc[0][i][j][r]);
                 }
