@@ -420,6 +420,30 @@ struct TileLoader {
     }
 };
 
+// A wave's staged 64x64 bf16 image (row stride RS elements, 16-byte aligned rows) -> dst[(row_base + r) * ld + col_base + c]:
+// a lane moves 8 consecutive columns of one row (16 bytes), 8 lanes per row, 8 rows per pass; ragged edges and
+// unaligned destinations fall back to 2-byte stores.
+template <int RS>
+__device__ __forceinline__ void flush_stage(const unsigned short* stage, int lane, void* dst, long ld, int row_base,
+                                            int row_lim, int col_base, int col_lim) {
+    const bool vec_ok = (ld % 8 == 0) && ((uintptr_t)dst % 16 == 0) && (col_base % 8 == 0);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int rl = it * 8 + (lane >> 3), cl = (lane & 7) * 8;
+        const int row = row_base + rl, col = col_base + cl;
+        const u32x4_t q = *reinterpret_cast<const u32x4_t*>(stage + rl * RS + cl);
+        if (row >= row_lim || col >= col_lim) continue;
+        unsigned short* out = reinterpret_cast<unsigned short*>(dst) + (long)row * ld + col;
+        if (vec_ok && col + 7 < col_lim) {
+            *reinterpret_cast<u32x4_t*>(out) = q;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (col + e < col_lim) out[e] = (unsigned short)((e & 1) ? (q[e >> 1] >> 16) : (q[e >> 1] & 0xffffu));
+        }
+    }
+}
+
 // XCD-aware bijective remap: blocks with equal (bid % 8) share an XCD's L2 (observed round-robin dispatch), so
 // give each of the 8 residue classes one contiguous chunk of the tile list.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -728,28 +752,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
         if (!p.c16) return;
         // (all of this wave's logits were read above: the in-place stores below cannot run ahead of a read)
         const int sub_m = m0 + wm * (BT / 2), sub_n = n0 + wn * (BT / 2);
-        auto flush = [&](void* dst, long ld, int row_base, int row_lim, int col_base, int col_lim) {
-            // the staged 64x64 image -> dst[(row_base + r) * ld + col_base + c]: a lane moves 8 consecutive columns of
-            // one row (16 bytes), 8 lanes per row, 8 rows per pass
-            const bool vec_ok = (ld % 8 == 0) && ((uintptr_t)dst % 16 == 0) && (col_base % 8 == 0);
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int rl = it * 8 + (lane >> 3), cl = (lane & 7) * 8;
-                const int row = row_base + rl, col = col_base + cl;
-                const u32x4_t q = *reinterpret_cast<const u32x4_t*>(stage + rl * RS + cl);
-                if (row >= row_lim || col >= col_lim) continue;
-                unsigned short* out = reinterpret_cast<unsigned short*>(dst) + (long)row * ld + col;
-                if (vec_ok && col + 7 < col_lim) {
-                    *reinterpret_cast<u32x4_t*>(out) = q;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (col + e < col_lim) out[e] = (unsigned short)((e & 1) ? (q[e >> 1] >> 16) : (q[e >> 1] & 0xffffu));
-                }
-            }
-        };
         __syncthreads();
-        flush(p.C, p.ldc, sub_m, p.M, sub_n, p.N);
+        flush_stage<RS>(stage, lane, p.C, p.ldc, sub_m, p.M, sub_n, p.N);
         if (p.ct) {
             __syncthreads();  // (uniform) the row-major image has been read
             // transposed image: stage[column][row], a lane's four consecutive rows of one column are one 8-byte write
@@ -761,13 +765,38 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
                     for (int rq = 0; rq < 4; ++rq)
                         *reinterpret_cast<u32x2*>(stage + (j * 32 + fr) * RS + i * 32 + 8 * rq + 4 * fk) = pk[i][j][rq];
             __syncthreads();
-            flush(p.ct, p.ldct, sub_n, p.N, sub_m, p.M);
+            flush_stage<RS>(stage, lane, p.ct, p.ldct, sub_n, p.N, sub_m, p.M);
         }
         return;
     }
     if (p.c16) {
         // bf16 C (cgn_gemm_desc.storage; host: no split-K, beta == 0). Its own loop nest: a c16 test inside the fp32
         // store loop below cost the fp32 products 13-25 % (the stores no longer issued back to back).
+        if constexpr (BT == 128) {
+            if (p.epilogue == CGN_EPI_LINEAR) {  // the vocabulary projection: staged through LDS like the fused epilogue
+                constexpr int RS = 72;
+                static_assert(4 * 64 * RS * 2 <= 4 * TILE * 4, "staging images must fit the operand buffers");
+                unsigned short* stage = reinterpret_cast<unsigned short*>(lds) + wave * (64 * RS);
+                __syncthreads();  // every wave is done with the operand images
+#pragma unroll
+                for (int j = 0; j < TW; ++j) {
+                    const int col = n0 + wn * (BT / 2) + j * 32 + fr;
+                    const int cc = col < p.N ? col : 0;
+                    const float b = (p.bias0 ? p.bias0[cc] : 0.f) + (p.bias1 ? p.bias1[cc] : 0.f);
+#pragma unroll
+                    for (int i = 0; i < TW; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                            const bf16x2 h = {(__bf16)(p.alpha * acc[0][i][j][r] + b), (__bf16)0.f};
+                            stage[rl * RS + j * 32 + fr] = (unsigned short)(__builtin_bit_cast(unsigned, h) & 0xffffu);
+                        }
+                }
+                __syncthreads();
+                flush_stage<RS>(stage, lane, p.C, p.ldc, m0 + wm * (BT / 2), p.M, n0 + wn * (BT / 2), p.N);
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TW; ++i) {
 #pragma unroll
