@@ -104,8 +104,9 @@ def gemm_symbol(sym):
     b = lambda v: "true" if v else "false"  # noqa: E731
     kstep = (16 if bt == 128 else 32) * (2 if bf16 else 1)
     # vec: bits 0/1 = 16-byte loads on A/B (the template's VEC), bits 2.. = fast K addressing mode (the template's FK)
-    return "cgn_gemm::gemm_kernel<%d, %s, %s, %d, %s, 2, %d, %s, %s, %d>" % (bt, b(a_kc), b(b_kc), vec & 3, b(exp), kstep,
-                                                                           b(smb), b(bf16), vec >> 2)
+    # bit 4 = A stored as bf16 (the template's A16)
+    return "cgn_gemm::gemm_kernel<%d, %s, %s, %d, %s, 2, %d, %s, %s, %d, %s>" % (
+        bt, b(a_kc), b(b_kc), vec & 3, b(exp), kstep, b(smb), b(bf16), (vec >> 2) & 3, b(vec & 16))
 
 
 def main():

@@ -123,7 +123,8 @@ int cgn_gemm_plan(const cgn_gemm_desc* desc /* host */, int32_t* tile, int32_t* 
 /* cgn_gemm_f32 with two hipEvent_t recorded on `stream` directly before and directly after the product's MFMA kernel
  * (the split-K reduce launch, if any, follows ev_stop): bench.py's live per-kernel timing, so that the event time is the
  * duration of the one kernel symbol rocprofv3 reports. vec_mode: nullable, receives the kernel's vector-load template
- * arguments (bit 0: A loads 16 bytes, bit 1: B, bits 2-3: fast K addressing mode). Measurement aid, no counterpart in the reference. */
+ * arguments (bit 0: A loads 16 bytes, bit 1: B, bits 2-3: fast K addressing mode, bit 4: A stored as bf16). Measurement aid,
+ * no counterpart in the reference. */
 int cgn_gemm_timed_f32(void* stream, const cgn_gemm_desc* desc /* host */, void* ev_start, void* ev_stop,
                        int32_t* vec_mode);
 

@@ -235,7 +235,7 @@ static int run_gemm(void* stream, const cgn_gemm_desc* d, hipEvent_t ev_start, h
 
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)tiles, (unsigned)splitk);
-    if (vec_mode) *vec_mode = (p.a_vec ? 1 : 0) | (p.b_vec ? 2 : 0) | (p.fastk << 2);
+    if (vec_mode) *vec_mode = (p.a_vec ? 1 : 0) | (p.b_vec ? 2 : 0) | (p.fastk << 2) | (p.a16 ? 16 : 0);
     if (ev_start && hipEventRecord(ev_start, s) != hipSuccess) return CGN_ERR_HIP_BASE + (int)hipGetLastError();
     if (p.a16)
         launch_gemm_a16(p, bt, b_kc, grid, s);
