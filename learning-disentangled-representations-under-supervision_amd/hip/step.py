@@ -569,7 +569,9 @@ class CGNStep:
         # bf16 mode: the logits-sized tensors (logits, dlogits and the transposed copy dW_fc reads) are HELD in bf16 when the
         # shapes allow 16-byte rows (ops.BF16_STORAGE; include/cgn_hip.h CGN_STORE_*): half the HBM bytes of the five
         # largest products' big operand. Everything else stays fp32.
-        store16 = ops.get_compute() == "bf16" and ops.BF16_STORAGE and V % 8 == 0 and NT % 8 == 0
+        # (the bf16-stored A operand needs 16-byte loads on its partners too: word table [V,E], W_fc [V,H], h history)
+        store16 = (ops.get_compute() == "bf16" and ops.BF16_STORAGE and V % 8 == 0 and NT % 8 == 0 and E % 4 == 0
+                   and Hg % 4 == 0 and table.stride(0) % 4 == 0)
         logits = _new((NT, V), dev, torch.bfloat16 if store16 else torch.float32)
         ops.gemm(h1, P["generator.fc.weight"].t(), logits, M=NT, K=Hg, a_m=h1ax, a_k=LIN, bias0=P["generator.fc.bias"])
         # ---- temperature softmax + CE (cgn.py:1086-1092) -------------------------------------------------------
