@@ -471,7 +471,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE];
 
     int tile_m, tile_n;
-    if (p.order == 0 && p.tiles_n < p.tiles_m) {
+    // the SHORTER tile axis runs fastest: tiles that are neighbours in the list (same XCD after the remap, resident
+    // together) share a panel of the operand that spans the long axis - dW_fc's 107 MB dlogits are fetched once per row
+    // panel instead of once per column tile (PMC: 445 -> see profiles/r02_pmc_traffic.txt; the kernel's time is unchanged)
+    if (p.tiles_n < p.tiles_m) {
         tile_n = t % p.tiles_n;
         tile_m = t / p.tiles_n;
     } else {
