@@ -71,7 +71,7 @@ struct GemmParams {
     int a_vec, b_vec;
     int a_transform, epilogue;
     int tiles_m, tiles_n;
-    int order;  // 0: remap over (split, tile), shorter tile axis fastest; 1: same remap, m fastest; 2: remap over tiles only
+    int order;  // 0 / 1: XCD remap over (split, tile); 2: remap over tiles only (the shorter tile axis runs fastest in all)
     float alpha, beta, a_scale, ep_inv_tau, ep_ce_scale;
     // fast K addressing (template flag FK): both K axes are plain and both operands span < 2^31 bytes, so a lane's byte
     // offset is fixed for the whole K loop and the K position is a scalar (buffer loads: voffset + soffset)
@@ -841,8 +841,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
 template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK = (BT == 128 ? 16 : 32), bool SMB = false,
           bool BF = false, int FK = 0, bool A16 = false>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
-    // Work item = (K split, tile). Default (order 2): the XCD remap runs over the tile list, m fastest (neighbouring
-    // tiles share the B, usually the weight, panel). Orders 0/1 remap over the whole (split, tile) list so that an XCD
+    // Work item = (K split, tile). Default (order 2): the XCD remap runs over the tile list, the shorter tile axis
+    // fastest (gemm_tile: neighbouring tiles share a panel of the operand that spans the long axis). Orders 0/1 remap over the whole (split, tile) list so that an XCD
     // owns whole K ranges of a split-K product: that cuts the memory-side fetch of the three tall-K products (PMC:
     // their 107 MB logits-sized operand is fetched ~4x, profiles/r01_pmc_traffic.txt) but measured no faster to 15 %
     // slower (tools/gemm_bench.py, GEMM_ORDER=0,1,2): these kernels are not fetch-bound, the Infinity Cache absorbs
