@@ -818,21 +818,54 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
         }
         return;
     }
+    // The common epilogues get LEAN loop nests of their own (one uniform branch picks the nest; per element: one bounds
+    // test, one fma, one store off a per-column base pointer). The all-purpose apply_epilogue() inlined 64 times made
+    // this part of the kernel ~60 KB of straight-line code: more than the instruction cache, run once per tile.
+    const int row_w = m0 + wm * (BT / 2) + 4 * fk, col_w = n0 + wn * (BT / 2) + fr;
+    if (p.splitk > 1) {  // K slab: the raw partial sums
+        float* wsp = p.ws + (long)split * p.M * p.ldw;
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+            const int col = col_w + j * 32;
+            if (col >= p.N) continue;
+#pragma unroll
+            for (int i = 0; i < TW; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (row < p.M) wsp[(long)row * p.ldw + col] = acc[0][i][j][r];
+                }
+        }
+        return;
+    }
+    if (p.epilogue == CGN_EPI_LINEAR && p.beta == 0.f) {  // C = alpha * acc + bias0 + bias1
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+            const int col = col_w + j * 32;
+            if (col >= p.N) continue;
+            const float b0 = p.bias0 ? p.bias0[col] : 0.f, b1 = p.bias1 ? p.bias1[col] : 0.f;
+            float* cp = p.C + col;
+#pragma unroll
+            for (int i = 0; i < TW; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (row < p.M) cp[(long)row * p.ldc] = (p.alpha * acc[0][i][j][r] + b0) + b1;  // (apply_epilogue's order)
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TW; ++i) {
 #pragma unroll
         for (int j = 0; j < TW; ++j) {
-            const int col = n0 + wn * (BT / 2) + j * 32 + fr;
+            const int col = col_w + j * 32;
             if (col >= p.N) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * (BT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2);
                 if (row >= p.M) continue;
-                if (p.splitk > 1) {
-                    p.ws[((long)split * p.M + row) * p.ldw + col] = acc[0][i][j][r];
-                } else {
-                    p.C[(long)row * p.ldc + col] = apply_epilogue(p, row, col, acc[0][i][j][r]);
-                }
+                p.C[(long)row * p.ldc + col] = apply_epilogue(p, row, col, acc[0][i][j][r]);
             }
         }
     }
