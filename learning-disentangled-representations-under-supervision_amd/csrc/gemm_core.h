@@ -855,6 +855,31 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
         }
         return;
     }
+    if (p.epilogue == CGN_EPI_LINEAR) {  // beta != 0: C = alpha * acc + bias0 + bias1 + beta * C (loads batched per slab)
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+            const int col = col_w + j * 32;
+            if (col >= p.N) continue;
+            const float b0 = p.bias0 ? p.bias0[col] : 0.f, b1 = p.bias1 ? p.bias1[col] : 0.f;
+            float* cp = p.C + col;
+#pragma unroll
+            for (int i = 0; i < TW; ++i) {
+                float old[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2);
+                    old[r] = cp[(long)(row < p.M ? row : m0) * p.ldc];  // (clamped: m0 < M always)
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (row < p.M) cp[(long)row * p.ldc] = ((p.alpha * acc[0][i][j][r] + b0) + b1) + p.beta * old[r];
+                }
+            }
+        }
+        return;
+    }
+    // what is left (the softmax backward epilogue of the variants without the dedicated fused one: small shapes)
 #pragma unroll
     for (int i = 0; i < TW; ++i) {
 #pragma unroll
