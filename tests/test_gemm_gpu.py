@@ -385,3 +385,20 @@ def test_gemm_bf16_stored_logits_chain(dev, M, V, E):
     db = torch.empty(V, device=dev)
     ops.colsum(logits, db)
     assert _rel(db, dl.sum(0)) < 2e-6
+
+
+@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("M,N,K", [(200, 300, 96), (129, 131, 40), (256, 256, 64)])
+def test_gemm_unsplit_epilogue_nests(dev, tile, M, N, K):
+    """The in-kernel epilogue nests of an unsplit product (csrc/gemm_core.h: linear, linear + beta): alpha, both biases
+    and beta * C against fp64, ragged edges included."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K + tile)
+    A, B = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g)
+    b0, b1, C0 = torch.randn(N, generator=g), torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    for beta in (0.0, 0.75):
+        out = C0.clone().to(dev)
+        ops.gemm(A.to(dev), B.to(dev), out, alpha=0.5, beta=beta, bias0=b0.to(dev), bias1=b1.to(dev), force_tile=tile,
+                 force_splitk=1)
+        ref = 0.5 * (A.double() @ B.double()) + b0.double() + b1.double() + beta * C0.double()
+        assert _rel(out, ref) < 2e-6, beta
