@@ -25,6 +25,7 @@ constexpr int NO_SIGNAL = 16;   // no drain + barrier + arrival add
 constexpr int H_FIRST = 32;     // h store issued BEFORE the gates / c stores, drained alone, signalled, then the rest
 constexpr int WAVE_SIGNAL = 64; // every storing wave signals for itself (no barrier before the add); target x4
 constexpr int NO_SLEEP = 128;   // poll without s_sleep
+constexpr int FAST_TANH = 512;  // tanh through one hardware exponential instead of libm's tanhf
 constexpr int SENTINEL = 256;   // no counters at all: the history buffer is pre-filled with a NaN pattern that no
                                 // computation produces, a wave re-loads the quads of ITS k range that still hold it
 
@@ -41,6 +42,11 @@ struct Params {
 };
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
+template <int PROBE>
+__device__ __forceinline__ float tanh_p(float x) {
+    if constexpr (PROBE & 512) return 1.f - 2.f / (1.f + __expf(2.f * x));
+    else return tanhf(x);
+}
 
 template <int PROBE>
 __device__ __forceinline__ bool group_wait(unsigned* cnt, unsigned target, unsigned* tmo) {
@@ -178,9 +184,9 @@ __global__ __launch_bounds__(NT) void probe_kernel(const Params p, unsigned* syn
                 for (int wv = 0; wv < NW; ++wv) v += red[wv][g * 4 + er][lane];
                 pre[g] = v + pre_x[g];
             }
-            const float ig = sigm(pre[0]), fg = sigm(pre[1]), gg = tanhf(pre[2]), og = sigm(pre[3]);
+            const float ig = sigm(pre[0]), fg = sigm(pre[1]), gg = tanh_p<PROBE>(pre[2]), og = sigm(pre[3]);
             const float cn = fg * c_reg + ig * gg;
-            const float hn = og * tanhf(cn);
+            const float hn = og * tanh_p<PROBE>(cn);
             c_reg = cn;
             float* go = sq.gates + ((long)eb * T + t) * 4 * H;
             float* hp = sq.hbuf + ((long)eb * (T + 1) + t + 1) * H + ej;
@@ -296,6 +302,7 @@ int main(int argc, char** argv) {
     run<WAVE_SIGNAL>("every storing wave signals for itself", p, sync, sync_bytes, grid);
     run<H_FIRST | WAVE_SIGNAL>("h first + per-wave signal", p, sync, sync_bytes, grid);
     run<H_FIRST | WAVE_SIGNAL | NO_SLEEP>("h first + per-wave signal + no sleep", p, sync, sync_bytes, grid);
+    run<FAST_TANH>("tanh through __expf", p, sync, sync_bytes, grid);
     run<SENTINEL>("sentinel hand-off: no counters, re-load what has not arrived", p, sync, sync_bytes, grid);
     run<SENTINEL | NO_GSTORE>("sentinel hand-off, no gates/c stores", p, sync, sync_bytes, grid);
     run<SENTINEL | NO_MFMA>("sentinel hand-off, no MFMA", p, sync, sync_bytes, grid);
