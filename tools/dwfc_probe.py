@@ -10,6 +10,7 @@ from ldrs_amd.hip import engine, ops
 from ldrs_amd.hip._lib import Axis
 
 dev = torch.device("cuda", 0)
+ops.WORKSPACE_BYTES = 512 << 20
 B, T, H, V = 64, 21, 512, 20000
 NT = B * T
 LIN = Axis(1, 0, 0)
@@ -39,4 +40,10 @@ def bench(fn):
 
 
 print("dW_fc  %7.1f us" % bench(lambda: ops.gemm(dlogits.t(), h1, G, N=H, K=NT, b_k=h1ax, b_n=LIN)))
+for sk in (2, 3, 4):
+    print("dW_fc split-K %d (product + reduce) %7.1f us" % (sk, bench(lambda: ops.gemm(dlogits.t(), h1, G, N=H, K=NT, b_k=h1ax,
+                                                                                     b_n=LIN, force_splitk=sk))))
+for sk in (2, 3):
+    print("fc split-K %d (product + reduce) %7.1f us" % (sk, bench(lambda: ops.gemm(h1, W.t(), logits, M=NT, K=H, a_m=h1ax,
+                                                                                  a_k=LIN, bias0=bias, force_splitk=sk))))
 print("fc     %7.1f us" % bench(lambda: ops.gemm(h1, W.t(), logits, M=NT, K=H, a_m=h1ax, a_k=LIN, bias0=bias)))
