@@ -375,11 +375,13 @@ class CGNStep:
         ops.copy2d(sr.c_final(), ctx[:, He:])
         mulv = _new((B, 2 * Z), self.dev)
         w2 = self._fused("e2.w", P)
+        # (compute="f32" in the bf16 mode too: the Mahalanobis z-loss is a difference of two codes (cgn.py:47-57) and
+        # amplifies any rounding of mu / logvar; the head is 2*B*2He*2Z FLOP, nothing)
         if w2 is not None:  # [mu | logvar] in one product (cgn.py:91-92)
-            ops.gemm(ctx, w2.t(), mulv, bias0=self._fused("e2.b", P))
+            ops.gemm(ctx, w2.t(), mulv, bias0=self._fused("e2.b", P), compute="f32")
         else:
-            ops.gemm(ctx, P["e2mu.weight"].t(), mulv[:, :Z], bias0=P["e2mu.bias"])
-            ops.gemm(ctx, P["e2logvar.weight"].t(), mulv[:, Z:], bias0=P["e2logvar.bias"])
+            ops.gemm(ctx, P["e2mu.weight"].t(), mulv[:, :Z], bias0=P["e2mu.bias"], compute="f32")
+            ops.gemm(ctx, P["e2logvar.weight"].t(), mulv[:, Z:], bias0=P["e2logvar.bias"], compute="f32")
         return dict(hw_out=hw_out, hw_saved=hw_saved, sf=sf, sr=sr, ctx=ctx, mulv=mulv, B=B, L=L)
 
     def _encoder_bwd(self, es, dmulv, param_grads):
@@ -394,12 +396,12 @@ class CGNStep:
         dmu, dlv = dmulv[:, :Z], dmulv[:, Z:]
         w2 = self._fused("e2.w", P)
         if w2 is not None:
-            ops.gemm(dmulv, w2, dctx)
+            ops.gemm(dmulv, w2, dctx, compute="f32")
             if param_grads:
                 self.later(0, lambda: engine.linear_bwd(ctx, w2, dmulv, self._fused("e2.w", G), self._fused("e2.b", G)))
         else:
-            ops.gemm(dmu, P["e2mu.weight"], dctx)
-            ops.gemm(dlv, P["e2logvar.weight"], dctx, beta=1.0)
+            ops.gemm(dmu, P["e2mu.weight"], dctx, compute="f32")
+            ops.gemm(dlv, P["e2logvar.weight"], dctx, beta=1.0, compute="f32")
             if param_grads:
                 self.later(0, lambda: (engine.linear_bwd(ctx, P["e2mu.weight"], dmu, G["e2mu.weight"], G["e2mu.bias"]),
                                        engine.linear_bwd(ctx, P["e2logvar.weight"], dlv, G["e2logvar.weight"],

@@ -127,10 +127,13 @@ def test_wake_sleep_step_matches_oracle(dev, name, B, calc_z):
     _step_parity(dev, name, B, calc_z, TOL)
 
 
-@pytest.mark.parametrize("name,B,calc_z", [("odd", 7, True), ("mid", 16, False), ("mid", 8, True), ("cfg2", 64, False)])
+@pytest.mark.parametrize("name,B,calc_z", [("odd", 7, True), ("mid", 16, False), ("mid", 8, True), ("cfg2", 64, False),
+                                           ("cfg4", 8, False), ("cfg4", 8, True)])
 def test_wake_sleep_step_bf16_mode(dev, name, B, calc_z):
     """North-star's optional bf16 mode (MFMA operands rounded to bf16 inside the GEMM kernels, fp32 accumulation and
-    fp32 everywhere else): every loss and every gradient tensor within 1e-2 of the fp64 oracle."""
+    fp32 everywhere else): every loss and every gradient tensor within 1e-2 of the fp64 oracle. BASELINE configs[3] is
+    STATED in this mode: the "cfg4" cases run it at full model size (vocab 50k, hidden 1024, seq len 40) with 8
+    sentences; its full batch of 256: test_cfg4_full_batch_properties[bf16]."""
     from ldrs_amd.hip import ops
     prev = ops.set_compute("bf16")
     try:
@@ -276,9 +279,7 @@ def _step_parity(dev, name, B, calc_z, TOL):
             if nm == "z_loss" and not calc_z:
                 assert float(a) == 0.0
                 continue
-            # bf16 mode: z_loss is a squared DIFFERENCE of two nearly equal codes (cgn.py:47-57), so the ~3e-3 error of the
-            # re-encoded code shows up amplified in it (measured 1.3e-2 on "odd", 4e-3 on "mid"); its bar is 3e-2
-            rep.add("loss", "encgen." + nm, step, rel(a, b), 3e-2 if (bf16 and nm == "z_loss") else TOL)
+            rep.add("loss", "encgen." + nm, step, rel(a, b), TOL)
         rep.add("grad", "g = d(79 CE + recon)/dz", step, rel(cap["g"], cap_o["g"]), GTOL)
         for key, okey, prefix in (("disc_grads", "disc_grads", "sentiment_discriminator."),
                                   ("gen_grads", "gen_grads", "generator."), ("enc_grads", "enc_grads", "")):
@@ -345,12 +346,25 @@ def _grads_of_one_step(model, cfg, data, masks, rows, gstep, dev):
     return grads, losses, c.cpu()
 
 
-def test_cfg4_full_batch_properties(dev):
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+def test_cfg4_full_batch_properties(dev, compute):
     """BASELINE.json configs[3] at FULL size (vocab 50k, seq len 40, hidden 1024, batch 256), where the fp64 oracle would
     need minutes: size-independent properties instead. Every loss of the step is a MEAN over the batch, so the
     gradients of the full batch are the average of the gradients of its two halves - computed by differently shaped
     launches of every kernel (other tile counts, split-K plans, batch tiles of the recurrences) from identical weights.
-    Bars: 1e-4 on every gradient tensor and loss (fp32 summation order only); the inferred codes c are identical."""
+    Bars: 1e-4 on every gradient tensor and loss (fp32 summation order only); the inferred codes c are identical.
+    In the bf16 mode (the mode configs[3] is stated in) the bar is the mode's 1e-2: operands are rounded element by
+    element, so halves and full batch multiply the same rounded values, but the bf16-STORED dlogits carry the 1/(B*T)
+    factor of their batch and the soft-embedding gradient is rounded at a different magnitude."""
+    from ldrs_amd.hip import ops
+    prev = ops.set_compute(compute)
+    try:
+        _cfg4_full_batch_properties(dev, 1e-4 if compute == "f32" else 1e-2, compute)
+    finally:
+        ops.set_compute(prev)
+
+
+def _cfg4_full_batch_properties(dev, bar, compute):
     from ldrs_amd.hip import ops
     ocfg, oracle, cfg, model = build("cfg4", dev)
     del oracle
@@ -371,11 +385,18 @@ def test_cfg4_full_batch_properties(dev):
     assert torch.equal(c_full, torch.cat([halves[0][2], halves[1][2]]))
     assert all(v == v and abs(v) < 1e6 for v in l_full), l_full
     for a, b0, b1 in zip(l_full, halves[0][1], halves[1][1]):
-        assert abs(a - 0.5 * (b0 + b1)) <= 1e-4 * max(1.0, abs(a)), (a, b0, b1)
+        assert abs(a - 0.5 * (b0 + b1)) <= bar * max(1.0, abs(a)), (a, b0, b1)
     worst = ("", 0.0)
     for n, gf in full.items():
         e = rel(0.5 * (halves[0][0][n] + halves[1][0][n]), gf)
         worst = max(worst, (n, e), key=lambda t: t[1])
-        assert e < 1e-4, (n, e)
+        assert e < bar, (n, e)
     assert ops.lstm_sticky_timeouts() == 0
-    print("cfg4 full batch: worst half/half vs full gradient error %.2e (%s)" % (worst[1], worst[0]))
+    line = "cfg4 full batch (%s): worst half/half vs full gradient error %.2e (%s)" % (compute, worst[1], worst[0])
+    print(line)
+    import os
+    d = os.environ.get("CGN_PARITY_REPORT")
+    if d:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "cfg4_full_batch_halves_%s.txt" % compute), "w") as f:
+            f.write(line + "\n")
