@@ -181,11 +181,15 @@ int cgn_lstm_seq_fwd_f32(void* stream, const cgn_lstm_fwd_seq* seqs /* host */, 
  * cgn_lstm_persistent_query: *sync_bytes = size of the caller-owned, 16-byte aligned device scratch `sync_ws` the
  * launch needs, or 0 when the shape is not eligible (H % 16, H <= 1024, nseq * ceil(B/(16*RT)) * H/16 workgroups <= CUs
  * of the current device for RT = 1, 2 or 4 row tiles per workgroup; H > 512 always takes the row-tiled kernels): use
- * the step kernels then, or one launch per sequence when a single sequence is eligible. Layout: sync_bytes - 128 bytes of counters plus the launch's timeout
- * word, zeroed by the library on the stream before each launch - after the stream has drained, word
- * (sync_bytes/4 - 64) is non-zero iff a bounded wait of THAT launch ran out (results invalid); and the LAST whole
- * 128-byte line of the buffer actually passed (sync_ws_bytes) is a STICKY timeout flag: set by any launch whose wait
- * ran out, never cleared by the library - the caller zeroes it once and can check a whole training run with one read.
+ * the step kernels then, or one launch per sequence when a single sequence is eligible. The CALLER zeroes sync_ws ONCE
+ * (hipMemset after allocation); the library never does: every launch leaves the arrival counters at zero again on its
+ * way out (the last workgroup of a hand-off group to leave re-arms them), so no memset sits in front of a launch and
+ * the entry points are plain kernel launches under hipGraph capture. The LAST whole 128-byte line of the buffer
+ * actually passed (sync_ws_bytes) is a STICKY timeout flag: set by any launch whose bounded wait ran out (results
+ * invalid from then on), never cleared by the library. While it is set every wait of every later launch on this
+ * sync_ws gives up after at most 64 polls (launches drain at once, their results are invalid, their counters still end
+ * at zero): fail-stop. The caller checks it at its host sync points and zeroes it to resume. (ABI 4 also had a
+ * per-launch timeout word, zeroed by a memset node before each launch: gone in ABI 5.)
  * Launches sharing one sync_ws must not overlap. */
 int cgn_lstm_persistent_query(int32_t nseq, int32_t B, int32_t T, int32_t H, int64_t* sync_bytes);
 int cgn_lstm_seq_fwd_persistent_f32(void* stream, const cgn_lstm_fwd_seq* seqs /* host */, int32_t nseq, int32_t B,
@@ -195,8 +199,9 @@ int cgn_lstm_seq_fwd_persistent_f32(void* stream, const cgn_lstm_fwd_seq* seqs /
  * callers that may not call hipMalloc - code under hipGraph capture, tight serving loops, harnesses that forbid it.
  * Same kernels, buffers and results as cgn_lstm_seq_fwd_persistent_f32, but the arrival counters / timeout word live in
  * a file-scope device array of the library (33,024 bytes per GPU, held until the process ends) instead of a caller-owned
- * sync_ws; the call allocates nothing (no hipMalloc / hipFree, no allocating library routine) and re-zeroes the counters
- * on `stream` itself. Limit: nseq * ceil(B/16) <= 256 counter groups (and the shape must be eligible per
+ * sync_ws; the call allocates nothing (no hipMalloc / hipFree, no allocating library routine): it is ONE kernel launch
+ * on `stream` (the array starts zeroed, every launch leaves its counters at zero). The FIRST call on a device resolves
+ * the array's device address (hipGetSymbolAddress) and must therefore be made outside stream capture. Limit: nseq * ceil(B/16) <= 256 counter groups (and the shape must be eligible per
  * cgn_lstm_persistent_query), else CGN_ERR_INVALID_ARG. Every call on a GPU shares that GPU's array: calls that overlap
  * on one GPU (different streams) race - serialise them. status: nullable device word, set to 1 by a launch whose bounded
  * wait ran out (results invalid), never cleared by the library; NULL keeps the flag in the library's own array. */

@@ -1,0 +1,5 @@
+// Library / ABI version (include/cgn_hip.h). A translation unit of its own: bumping it rebuilds nothing else.
+//   5: persistent LSTM scratch is zeroed once by the caller (no per-launch memset, no per-launch timeout word)
+#include "common.h"
+
+extern "C" int cgn_abi_version(void) { return 5; }

@@ -100,8 +100,6 @@ int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out
 
 }  // namespace
 
-extern "C" int cgn_abi_version(void) { return 4; }
-
 extern "C" void cgn_debug_set_stages(int v) {
     g_stages = v & 15;  // kept for ABI stability: the stage count is fixed at 2 since round 1
     g_order = (v >> 4) & 15;

@@ -69,12 +69,17 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 struct WorkId {
     int jt, bt, seq;
 };
-__device__ __forceinline__ WorkId lstm_work(int nj, int nb, int nseq) {
-    const int nwg = nj * nb * nseq;
+// blockIdx.x -> position in a work list of nwg items such that the blocks of one XCD residue class (b % 8) take a
+// CONTIGUOUS range of the list; bijective for every nwg
+__device__ __forceinline__ int xcd_contiguous(int nwg, int identity = 0) {
     const int bid = blockIdx.x;
+    if (identity) return bid;  // CGN_LSTM_XCD_MAP=0: the round-2 placement (A/B measurements only)
     const int qq = nwg / 8, rr = nwg % 8;
     const int xcd = bid % 8, idx = bid / 8;
-    const int w = ((xcd < rr) ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;  // bijective
+    return ((xcd < rr) ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+}
+__device__ __forceinline__ WorkId lstm_work(int nj, int nb, int nseq) {
+    const int w = xcd_contiguous(nj * nb * nseq);
     WorkId o;
     o.jt = w / (nb * nseq);
     const int rest = w % (nb * nseq);
@@ -296,29 +301,52 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_step_bwd_kernel(const BwdParams 
 //   consumer: ONE lane polls the counter (relaxed sc1 loads, bounded) until NJ*step arrivals, workgroup barrier,
 //             then EVERY load of the handed-off rows is an sc1 buffer load (L2-served, never this CU's L1).
 // This is the all-sc1 hand-off of MI355X_MICROARCH.md (visibility table, first row): placement-independent, no
-// L1/L2 invalidate per step. Counters and the timeout word are zeroed by a memset node before each launch.
+// L1/L2 invalidate per step.
+// Placement (speed only): the group-major work list is dealt so that every XCD residue class of blockIdx takes a
+// contiguous range of it (xcd_contiguous) - at cfg2 each group of 32 workgroups IS one XCD's 32 blocks. sc1 stores drop
+// their line from the L2, so the first sc1 load of an h_t row on an XCD fetches it over the fabric and the other
+// workgroups of that XCD hit the L2: with a group spread over all 8 XCDs every row crossed the fabric 8 times.
+// Counters: the caller zeroes the scratch ONCE; every launch leaves its counters at zero again (persist_checkout: the
+// last workgroup of a hand-off domain to leave re-arms them), so no memset node sits in front of a launch.
 // Residency: grid <= number of CUs (host check), 512-thread workgroups; every spin is bounded: a wait that runs out
-// raises the timeout word, which ends every other wait, so the grid always drains (results are then invalid and the
-// host-visible word says so).
+// raises the STICKY word, which ends every other wait of this and of every later launch after at most 64 polls, so the
+// grid always drains (results are invalid from then on, the host-visible word says so, and the caller clears it).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr unsigned PERSIST_SPIN_LIMIT = 1u << 19;
 constexpr int SYNC_STRIDE = 32;  // u32 words per counter: one 128-byte line each
+constexpr int SYNC_EXIT = 16;    // word of a domain's first counter line that counts the workgroups that have left
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ bool group_wait(unsigned* cnt, unsigned target, unsigned* tmo, unsigned* sticky) {
+__device__ __forceinline__ bool group_wait(unsigned* cnt, unsigned target, unsigned* sticky) {
     unsigned spins = 0;
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
         ++spins;
         if (spins > PERSIST_SPIN_LIMIT ||
-            ((spins & 63u) == 0u && __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-            __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ((spins & 63u) == 0u && __hip_atomic_load(sticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
             __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // never cleared by the library
             return false;
         }
     }
     return true;
+}
+
+// Last act of every workgroup of a persistent launch (reached on the timeout path too): check out of the hand-off
+// domain; the last of its `members` to leave sets the domain's counters and the exit word back to zero. Nobody polls
+// them any more (every member has left its time loop), and this workgroup's own arrival adds have been performed
+// (vmcnt(0)) before it checks out, so no add can land behind the reset.
+__device__ __forceinline__ void persist_checkout(unsigned* c0, unsigned* c1, unsigned members) {
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned* ex = c0 + SYNC_EXIT;
+        const unsigned old = __hip_atomic_fetch_add(ex, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == members - 1u) {
+            __hip_atomic_store(c0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c1) __hip_atomic_store(c1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ex, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 __device__ __forceinline__ f32x4 ld4_sc1(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
@@ -343,12 +371,11 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_kernel(const FwdPara
     __shared__ int s_ok;
     const int B = p.B, T = p.T, H = p.H;
     const int NJ = H / 16, NB = (B + 15) / 16;
-    const int wid = blockIdx.x;
+    const int wid = xcd_contiguous(gridDim.x, p.step);  // p.step: 1 = identity placement (A/B runs)
     const int seq = wid / (NB * NJ);
     const int bt = (wid % (NB * NJ)) / NJ, jt = wid % NJ;
     const FwdSeq& sq = p.s[seq];
     unsigned* cnt = sync + (seq * NB + bt) * SYNC_STRIDE;
-    unsigned* tmo = sync + p.nseq * NB * SYNC_STRIDE;
     const int j0 = jt * 16, b0 = bt * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, q = lane >> 4;
@@ -411,7 +438,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_kernel(const FwdPara
             for (int g = 0; g < 4; ++g) pre_x[g] = xg[g * H];
         }
         if (step > 0) {
-            if (threadIdx.x == 0) s_ok = group_wait(cnt, (unsigned)(NJ * step), tmo, sticky) ? 1 : 0;
+            if (threadIdx.x == 0) s_ok = group_wait(cnt, (unsigned)(NJ * step), sticky) ? 1 : 0;
             __syncthreads();
             if (!s_ok) break;  // workgroup-uniform
         }
@@ -467,6 +494,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_kernel(const FwdPara
         if (threadIdx.x == 0 && step + 1 < T)
             __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    persist_checkout(cnt, nullptr, (unsigned)NJ);
 }
 
 // CPW: chunks (of 16 k over K = 4H) per wave held in registers; H <= 32 * CPW.
@@ -477,12 +505,11 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdPara
     const int B = p.B, T = p.T, H = p.H;
     const int K = 4 * H;
     const int NJ = H / 16, NB = (B + 15) / 16;
-    const int wid = blockIdx.x;
+    const int wid = xcd_contiguous(gridDim.x, p.step);  // p.step: 1 = identity placement (A/B runs)
     const int seq = wid / (NB * NJ);
     const int bt = (wid % (NB * NJ)) / NJ, jt = wid % NJ;
     const BwdSeq& sq = p.s[seq];
     unsigned* cnt = sync + (seq * NB + bt) * SYNC_STRIDE;
-    unsigned* tmo = sync + p.nseq * NB * SYNC_STRIDE;
     const int j0 = jt * 16, b0 = bt * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, q = lane >> 4;
@@ -533,7 +560,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdPara
 
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         if (step > 0) {
-            if (threadIdx.x == 0) s_ok = group_wait(cnt, (unsigned)(NJ * step), tmo, sticky) ? 1 : 0;
+            if (threadIdx.x == 0) s_ok = group_wait(cnt, (unsigned)(NJ * step), sticky) ? 1 : 0;
             __syncthreads();
             if (!s_ok) break;  // workgroup-uniform
             const int aoff = (bA * T + t_next) * K * 4;
@@ -573,6 +600,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdPara
             __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (evalid) sq.dc_state[(long)eb * H + ej] = dc_reg;
+    persist_checkout(cnt, nullptr, (unsigned)NJ);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -589,12 +617,11 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdP
     __shared__ int s_ok;
     const int B = p.B, T = p.T, H = p.H;
     const int NJ = H / 16, NB = (B + 16 * RT - 1) / (16 * RT);
-    const int wid = blockIdx.x;
+    const int wid = xcd_contiguous(gridDim.x, p.step);  // p.step: 1 = identity placement (A/B runs)
     const int seq = wid / (NB * NJ);
     const int bt = (wid % (NB * NJ)) / NJ, jt = wid % NJ;
     const FwdSeq& sq = p.s[seq];
     unsigned* cnt = sync + (seq * NB + bt) * SYNC_STRIDE;
-    unsigned* tmo = sync + p.nseq * NB * SYNC_STRIDE;
     const int j0 = jt * 16, b0 = bt * 16 * RT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, q = lane >> 4;
@@ -657,7 +684,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdP
             for (int g = 0; g < 4; ++g) pre_x[rt][g] = xg[g * H];
         }
         if (step > 0) {
-            if (threadIdx.x == 0) s_ok = group_wait(cnt, (unsigned)(NJ * step), tmo, sticky) ? 1 : 0;
+            if (threadIdx.x == 0) s_ok = group_wait(cnt, (unsigned)(NJ * step), sticky) ? 1 : 0;
             __syncthreads();
             if (!s_ok) break;  // workgroup-uniform
         }
@@ -719,6 +746,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdP
         if (threadIdx.x == 0 && step + 1 < T)
             __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    persist_checkout(cnt, nullptr, (unsigned)NJ);
 }
 
 // CPW: chunks (of 16 k over K = 4H) per wave held in registers (H <= 32 * CPW); the gradient rows are loaded CB chunks at
@@ -732,12 +760,11 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_rt_kernel(const BwdP
     const int B = p.B, T = p.T, H = p.H;
     const int K = 4 * H;
     const int NJ = H / 16, NB = (B + 16 * RT - 1) / (16 * RT);
-    const int wid = blockIdx.x;
+    const int wid = xcd_contiguous(gridDim.x, p.step);  // p.step: 1 = identity placement (A/B runs)
     const int seq = wid / (NB * NJ);
     const int bt = (wid % (NB * NJ)) / NJ, jt = wid % NJ;
     const BwdSeq& sq = p.s[seq];
     unsigned* cnt = sync + (seq * NB + bt) * SYNC_STRIDE;
-    unsigned* tmo = sync + p.nseq * NB * SYNC_STRIDE;
     const int j0 = jt * 16, b0 = bt * 16 * RT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, q = lane >> 4;
@@ -782,7 +809,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_rt_kernel(const BwdP
         const int slot_prev = sq.reverse ? t + 1 : t;
         const int slot_out = sq.reverse ? t : t + 1;
         if (step > 0) {
-            if (threadIdx.x == 0) s_ok = group_wait(cnt, (unsigned)(NJ * step), tmo, sticky) ? 1 : 0;
+            if (threadIdx.x == 0) s_ok = group_wait(cnt, (unsigned)(NJ * step), sticky) ? 1 : 0;
             __syncthreads();
             if (!s_ok) break;  // workgroup-uniform
         }
@@ -850,6 +877,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_rt_kernel(const BwdP
         const int eb = b0 + rt * 16 + (lane >> 4) * 4 + er;
         if (wave < 4 && eb < B) sq.dc_state[(long)eb * H + ej] = dc_reg[rt];
     }
+    persist_checkout(cnt, nullptr, (unsigned)NJ);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -879,7 +907,7 @@ struct Fwd2Params {
     float* hbuf[2];
     float* cbuf[2];
     float* gates[2];
-    int B, T, H;
+    int B, T, H, flat;
 };
 
 // CPH: chunks (of 16 k) per wave and per operand half held in registers: H <= 128 * CPH. Every wave owns CPH chunks
@@ -893,12 +921,12 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_fwd_kernel(const Fwd2Pa
     __shared__ int s_ok;
     const int B = p.B, T = p.T, H = p.H;
     const int NJ = H / 16, NB = (B + 15) / 16;
-    const int wid = blockIdx.x;
-    const int layer = wid / (NB * NJ);
-    const int bt = (wid % (NB * NJ)) / NJ, jt = wid % NJ;
+    // layer-0 and layer-1 groups of one batch tile on NEIGHBOURING list ranges: (bt, layer, jt)
+    const int wid = xcd_contiguous(gridDim.x, p.flat);
+    const int layer = (wid / NJ) % 2;
+    const int bt = wid / (2 * NJ), jt = wid % NJ;
     unsigned* cnt_own = sync + (layer * NB + bt) * SYNC_STRIDE;
     unsigned* cnt_below = sync + bt * SYNC_STRIDE;  // layer 0's group of the same batch tile
-    unsigned* tmo = sync + 2 * NB * SYNC_STRIDE;
     const int j0 = jt * 16, b0 = bt * 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: chunk ranges are wave-uniform
@@ -973,7 +1001,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_fwd_kernel(const Fwd2Pa
         for (int g = 0; g < 4; ++g) acc[g] = {0.f, 0.f, 0.f, 0.f};
         // ---- phase A (layer 1): W_ih1 · h0_t; h0_t sits in slot t+1 of layer 0's history
         if (layer == 1) {
-            if (threadIdx.x == 0) s_ok = group_wait(cnt_below, (unsigned)(NJ * (t + 1)), tmo, sticky) ? 1 : 0;
+            if (threadIdx.x == 0) s_ok = group_wait(cnt_below, (unsigned)(NJ * (t + 1)), sticky) ? 1 : 0;
             __syncthreads();
             if (!s_ok) break;  // workgroup-uniform
             const int off = (bA * (T + 1) + t + 1) * H * 4 + q * 16;
@@ -993,7 +1021,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_fwd_kernel(const Fwd2Pa
         }
         // ---- phase B: W_hh · h_{t-1} of this layer (slot t of its own history); h_{-1} = 0 contributes nothing
         if (t > 0) {
-            if (threadIdx.x == 0) s_ok = group_wait(cnt_own, (unsigned)(NJ * t), tmo, sticky) ? 1 : 0;
+            if (threadIdx.x == 0) s_ok = group_wait(cnt_own, (unsigned)(NJ * t), sticky) ? 1 : 0;
             __syncthreads();
             if (!s_ok) break;  // workgroup-uniform
             const int off = (bA * (T + 1) + t) * H * 4 + q * 16;
@@ -1045,6 +1073,8 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_fwd_kernel(const Fwd2Pa
         if (threadIdx.x == 0 && (layer == 0 || t + 1 < T))
             __hip_atomic_fetch_add(cnt_own, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // hand-off domain = both layers' groups of this batch tile (layer 1 polls layer 0's counter too)
+    persist_checkout(sync + bt * SYNC_STRIDE, sync + (NB + bt) * SYNC_STRIDE, 2u * (unsigned)NJ);
 }
 
 struct Bwd2Params {
@@ -1056,7 +1086,7 @@ struct Bwd2Params {
     const float* dh_ext1;
     float* dgates[2];
     long dh_bs, dh_ts;
-    int B, T, H;
+    int B, T, H, flat;
 };
 
 // role 0 = the TOP layer (layer 1: dh1_t = dH_ext[t] + W_hh1ᵀ·dg1_{t+1}), role 1 = the BOTTOM layer (layer 0:
@@ -1070,13 +1100,12 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_bwd_kernel(const Bwd2Pa
     const int B = p.B, T = p.T, H = p.H;
     const int K4 = 4 * H;
     const int NJ = H / 16, NB = (B + 15) / 16;
-    const int wid = blockIdx.x;
-    const int role = wid / (NB * NJ);  // 0: layer 1 (top), 1: layer 0 (bottom)
+    const int wid = xcd_contiguous(gridDim.x, p.flat);  // list order (bt, role, jt), as in the forward kernel
+    const int role = (wid / NJ) % 2;  // 0: layer 1 (top), 1: layer 0 (bottom)
     const int layer = 1 - role;
-    const int bt = (wid % (NB * NJ)) / NJ, jt = wid % NJ;
+    const int bt = wid / (2 * NJ), jt = wid % NJ;
     unsigned* cnt_own = sync + (role * NB + bt) * SYNC_STRIDE;
     unsigned* cnt_top = sync + bt * SYNC_STRIDE;
-    unsigned* tmo = sync + 2 * NB * SYNC_STRIDE;
     const int j0 = jt * 16, b0 = bt * 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: chunk ranges are wave-uniform
@@ -1134,7 +1163,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_bwd_kernel(const Bwd2Pa
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         // ---- phase A (bottom layer): W_ih1ᵀ · dg1_t, the top layer's gate gradients of THIS timestep
         if (role == 1) {
-            if (threadIdx.x == 0) s_ok = group_wait(cnt_top, (unsigned)(NJ * (step + 1)), tmo, sticky) ? 1 : 0;
+            if (threadIdx.x == 0) s_ok = group_wait(cnt_top, (unsigned)(NJ * (step + 1)), sticky) ? 1 : 0;
             __syncthreads();
             if (!s_ok) break;  // workgroup-uniform
             const int off = (bA * T + t) * K4 * 4 + q * 16;
@@ -1153,7 +1182,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_bwd_kernel(const Bwd2Pa
         }
         // ---- phase B: W_hhᵀ · dg_{t+1} of this layer; the first step has none
         if (step > 0) {
-            if (threadIdx.x == 0) s_ok = group_wait(cnt_own, (unsigned)(NJ * step), tmo, sticky) ? 1 : 0;
+            if (threadIdx.x == 0) s_ok = group_wait(cnt_own, (unsigned)(NJ * step), sticky) ? 1 : 0;
             __syncthreads();
             if (!s_ok) break;  // workgroup-uniform
             const int off = (bA * T + t + 1) * K4 * 4 + q * 16;
@@ -1192,9 +1221,16 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_bwd_kernel(const Bwd2Pa
         if (threadIdx.x == 0 && (role == 0 || step + 1 < T))
             __hip_atomic_fetch_add(cnt_own, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    persist_checkout(sync + bt * SYNC_STRIDE, sync + (NB + bt) * SYNC_STRIDE, 2u * (unsigned)NJ);
 }
 
 int g_num_cus[16] = {0};
+
+// CGN_LSTM_XCD_MAP=0 keeps blockIdx order (hand-off groups spread over all XCDs) for A/B measurements
+int xcd_identity() {
+    static const int v = [] { const char* e = getenv("CGN_LSTM_XCD_MAP"); return (e && e[0] == '0') ? 1 : 0; }();
+    return v;
+}
 
 int device_cus() {
     int dev = 0;
@@ -1226,10 +1262,10 @@ int persist_rt(int nseq, int B, int T, int H) {
     return 0;
 }
 
-// scratch layout: one 128-byte line per group counter, one for the per-launch timeout word (all zeroed by every launch),
-// and, as the LAST line of whatever the caller passed, a sticky timeout flag that the library sets and never clears
-long persist_zero_bytes(int nseq, int B) { return ((long)nseq * cgn_cdiv(B, 16) + 1) * SYNC_STRIDE * 4; }
-long persist_sync_bytes(int nseq, int B) { return persist_zero_bytes(nseq, B) + SYNC_STRIDE * 4; }
+// scratch layout: one 128-byte line per group (word 0: arrival counter, word 16: exit counter of its hand-off domain),
+// zeroed ONCE by the caller and left at zero by every launch; one reserved line; and, as the LAST line of whatever the
+// caller passed, the sticky timeout flag that the library sets and never clears
+long persist_sync_bytes(int nseq, int B) { return ((long)nseq * cgn_cdiv(B, 16) + 2) * SYNC_STRIDE * 4; }
 
 }  // namespace
 
@@ -1348,10 +1384,8 @@ extern "C" int cgn_lstm_seq_fwd_persistent_f32(void* stream, const cgn_lstm_fwd_
         CGN_CHECK_ARG(((uintptr_t)s.hbuf % 16 == 0) && ((uintptr_t)s.w_hh % 16 == 0));
         p.s[i] = {s.xg, s.xg_extra, s.w_hh, s.hbuf, s.cbuf, s.gates, s.reverse, s.init_zero};
     }
-    p.B = B; p.T = T; p.H = H; p.nseq = nseq; p.step = 0;
+    p.B = B; p.T = T; p.H = H; p.nseq = nseq; p.step = xcd_identity();
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sync_ws, 0, (size_t)persist_zero_bytes(nseq, B), st) != hipSuccess)
-        return CGN_ERR_HIP_BASE + (int)hipGetLastError();
     unsigned* sticky = (unsigned*)((char*)sync_ws + (sync_ws_bytes / 128 - 1) * 128);
     dim3 grid(nseq * cgn_cdiv(B, 16 * rt) * (H / 16));
     unsigned* sw = (unsigned*)sync_ws;
@@ -1425,11 +1459,9 @@ extern "C" int cgn_lstm_seq_fwd_persistent_noalloc_f32(void* stream, const cgn_l
         CGN_CHECK_ARG(((uintptr_t)s.hbuf % 16 == 0) && ((uintptr_t)s.w_hh % 16 == 0));
         p.s[i] = {s.xg, s.xg_extra, s.w_hh, s.hbuf, s.cbuf, s.gates, s.reverse, s.init_zero};
     }
-    p.B = B; p.T = T; p.H = H; p.nseq = nseq; p.step = 0;
+    p.B = B; p.T = T; p.H = H; p.nseq = nseq; p.step = xcd_identity();
     hipStream_t st = (hipStream_t)stream;
-    // counters + timeout word start at zero for every call (the array keeps the last call's contents)
-    if (hipMemsetAsync(scratch, 0, (size_t)persist_zero_bytes(nseq, B), st) != hipSuccess)
-        return CGN_ERR_HIP_BASE + (int)hipGetLastError();
+    // the counters are at zero: the array starts zeroed and every launch re-arms them on its way out (persist_checkout)
     unsigned* sticky = status ? status : scratch + (NOALLOC_LINES - 1) * SYNC_STRIDE;
     dim3 grid(nseq * cgn_cdiv(B, 16) * (H / 16));
     if (H <= 256)
@@ -1457,10 +1489,8 @@ extern "C" int cgn_lstm_seq_bwd_persistent_f32(void* stream, const cgn_lstm_bwd_
         p.s[i] = {s.w_hh_t, s.w_hh, s.cbuf, s.gates, s.dh_ext, s.dh_seed, s.dgates, s.dc_state, s.dh_bs, s.dh_ts,
                   s.reverse};
     }
-    p.B = B; p.T = T; p.H = H; p.nseq = nseq; p.step = 0;
+    p.B = B; p.T = T; p.H = H; p.nseq = nseq; p.step = xcd_identity();
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sync_ws, 0, (size_t)persist_zero_bytes(nseq, B), st) != hipSuccess)
-        return CGN_ERR_HIP_BASE + (int)hipGetLastError();
     unsigned* sticky = (unsigned*)((char*)sync_ws + (sync_ws_bytes / 128 - 1) * 128);
     dim3 grid(nseq * cgn_cdiv(B, 16 * rt) * (H / 16));
     unsigned* sw = (unsigned*)sync_ws;
@@ -1503,10 +1533,8 @@ extern "C" int cgn_lstm2_fwd_persistent_f32(void* stream, const cgn_lstm2_fwd* d
     p.b_ih1 = d->b_ih1; p.b_hh1 = d->b_hh1;
     p.hbuf[0] = d->hbuf0; p.cbuf[0] = d->cbuf0; p.gates[0] = d->gates0;
     p.hbuf[1] = d->hbuf1; p.cbuf[1] = d->cbuf1; p.gates[1] = d->gates1;
-    p.B = B; p.T = T; p.H = H;
+    p.B = B; p.T = T; p.H = H; p.flat = xcd_identity();
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sync_ws, 0, (size_t)persist_zero_bytes(2, B), st) != hipSuccess)
-        return CGN_ERR_HIP_BASE + (int)hipGetLastError();
     unsigned* sticky = (unsigned*)((char*)sync_ws + (sync_ws_bytes / 128 - 1) * 128);
     dim3 grid(2 * cgn_cdiv(B, 16) * (H / 16));
     if (H <= 256)
@@ -1532,10 +1560,8 @@ extern "C" int cgn_lstm2_bwd_persistent_f32(void* stream, const cgn_lstm2_bwd* d
     p.cbuf[0] = d->cbuf0; p.gates[0] = d->gates0; p.cbuf[1] = d->cbuf1; p.gates[1] = d->gates1;
     p.dh_ext1 = d->dh_ext1; p.dh_bs = d->dh_bs; p.dh_ts = d->dh_ts;
     p.dgates[0] = d->dgates0; p.dgates[1] = d->dgates1;
-    p.B = B; p.T = T; p.H = H;
+    p.B = B; p.T = T; p.H = H; p.flat = xcd_identity();
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sync_ws, 0, (size_t)persist_zero_bytes(2, B), st) != hipSuccess)
-        return CGN_ERR_HIP_BASE + (int)hipGetLastError();
     unsigned* sticky = (unsigned*)((char*)sync_ws + (sync_ws_bytes / 128 - 1) * 128);
     dim3 grid(2 * cgn_cdiv(B, 16) * (H / 16));
     if (H <= 256)

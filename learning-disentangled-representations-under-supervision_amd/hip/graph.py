@@ -1,9 +1,13 @@
 """The wake-sleep step as a replayable hipGraph.
 
-Why: the step is ~350 kernel launches of 3-400 us each; issued one by one from Python the host needs as long to launch
-them as the MI355X needs to run them. Captured once into a hipGraph the whole step is one launch, and because the
-graph carries the dependency edges of the side streams (CGNStep.side/join), the latency-bound LSTM recurrences and the
-parameter-gradient GEMMs overlap with the dX chain.
+Why: the step is ~140 kernel launches of 3-270 us each; issued one by one from Python the host needs longer to launch
+them than the MI355X needs to run them. The step is captured once and replayed as ONE hipGraph PER BRANCH
+(_BranchRecorder): the main chain is cut wherever CGNStep.side() forks or join() joins, every side region is a graph of
+its own, and a replay launches them in recorded order on the caller's stream and two explicit side streams with events
+for fork and join - so the discriminator step runs beside the encoder forward and the parameter-gradient GEMMs beside
+the dX chain by the program's decision, not the runtime's. (Round 1 captured one graph with internal branches; ROCm
+mostly serialised them and once mis-ordered a three-successor node.) tests/test_graph_fullsize_gpu.py holds this replay
+to the eager step at the benchmark's sizes.
 
 What changes from call to call lives in device memory, not in kernel arguments:
   * the batch: static input tensors, refreshed with copy_() before a replay;

@@ -624,9 +624,10 @@ def embedding_bwd(idx, dx, dtable, beta=0.0):
     _call("cgn_embedding_bwd_f32", dx.device, _ptr(idx), _ptr(dx), n, V, E, beta, _ptr(dtable), _ptr(ws), ws.numel() * 4)
 
 
-# Persistent LSTM launches (one launch per sequence pass, csrc/lstm.hip) need a small zeroed scratch for their arrival
-# counters: one per (device, stream), like the split-K workspace. LSTM_PERSISTENT=False (or CGN_LSTM_PERSISTENT=0)
-# forces the one-launch-per-timestep kernels, which take every shape.
+# Persistent LSTM launches (one launch per sequence pass, csrc/lstm.hip) need a small scratch for their arrival counters,
+# zeroed ONCE here (every launch leaves its counters at zero again): one per (device, stream), like the split-K
+# workspace. LSTM_PERSISTENT=False (or CGN_LSTM_PERSISTENT=0) forces the one-launch-per-timestep kernels, which take
+# every shape.
 import os as _os
 LSTM_PERSISTENT = _os.environ.get("CGN_LSTM_PERSISTENT", "1") != "0"
 _lstm_sync = {}
@@ -662,10 +663,14 @@ def lstm_persistent_group(nseq, B, T, H, dev):
     return 1 if nseq > 1 and lstm_persistent_bytes(1, B, T, H, dev) else 0
 
 
-def lstm_timeout_word(dev, nseq, B, T, H):
-    """The timeout word of the last persistent launch of this shape on the current stream (0 = every wait was met)."""
-    n = lstm_persistent_bytes(lstm_persistent_group(nseq, B, T, H, dev) or nseq, B, T, H, dev)
-    return int(_lstm_sync_ws(dev)[n // 4 - 64].item()) if n else 0
+def lstm_counters_at_rest(dev=None):
+    """True when every arrival / exit counter of every persistent-LSTM scratch buffer (of `dev`, or of all devices) reads
+    zero - the state each launch must leave behind (csrc/lstm.hip persist_checkout), timed-out launches included.
+    Synchronises; for tests."""
+    idx = None if dev is None else (torch.device(dev).index if torch.device(dev).index is not None
+                                    else torch.cuda.current_device())
+    torch.cuda.synchronize()
+    return all(int(ws[:-32].abs().max().item()) == 0 for (i, _), ws in _lstm_sync.items() if idx is None or i == idx)
 
 
 def lstm_sticky_timeouts():

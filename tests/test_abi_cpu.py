@@ -46,7 +46,47 @@ def test_library_loads_and_exports_every_symbol():
     lib = _lib.load()
     for name in _declarations():
         assert hasattr(lib, name), "libcgn_hip.so does not export %s" % name
-    assert lib.cgn_abi_version() == 4
+    assert lib.cgn_abi_version() == _source_abi_version()
+
+
+def _source_abi_version():
+    src = open(os.path.join(_lib.PKG_DIR, "csrc", "abi.hip")).read()
+    return int(re.search(r"cgn_abi_version\(void\)\s*\{\s*return\s+(\d+)\s*;", src).group(1))
+
+
+def _header_struct_fields(cname):
+    """Field names of `typedef struct <cname> { ... }` in the header, in declaration order."""
+    text = re.sub(r"/\*.*?\*/", " ", open(HEADER).read(), flags=re.S)
+    body = re.search(r"typedef\s+struct\s+%s\s*\{(.*?)\}\s*%s\s*;" % (cname, cname), text, flags=re.S).group(1)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        first, *rest = decl.split(",")
+        names.append(re.search(r"(\w+)\s*(?:\[\w*\])?\s*$", first).group(1))
+        names += [re.search(r"(\w+)", r_).group(1) for r_ in rest]
+    return names
+
+
+def test_integration_md_shows_the_shipped_abi():
+    """INTEGRATION.md §B is what a maintainer of the reference copies: its version assert and its cgn_gemm_desc /
+    cgn_axis field lists must be the header's (round 2 shipped a document one ABI behind, 16 bytes short)."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index("<!-- ABI:BEGIN"):doc.index("<!-- ABI:END -->")]
+    assert int(re.search(r"cgn_abi_version\(\) == (\d+)", block).group(1)) == _source_abi_version()
+    assert "cgn_abi_version() ==" not in doc.replace(block, ""), "a second, hand-written version assert"
+    for pyname, cname, cls in (("Axis", "cgn_axis", _lib.Axis), ("GemmDesc", "cgn_gemm_desc", _lib.GemmDesc)):
+        m = re.search(r"class %s\(C\.Structure\):.*?_fields_ = \[(.*?)\]\n" % pyname, block, flags=re.S)
+        fields = re.findall(r'\("(\w+)",\s*([\w.]+)\)', m.group(1))
+        assert [f for f, _ in fields] == _header_struct_fields(cname), pyname
+        assert [f for f, _ in fields] == [f for f, _ in cls._fields_], pyname
+        ns = {"C": C, "Axis": _lib.Axis}
+        doc_cls = type(pyname, (C.Structure,), {"_fields_": [(f, eval(t, ns)) for f, t in fields]})
+        assert C.sizeof(doc_cls) == C.sizeof(cls), pyname
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_integration_abi.py"), "--check"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -63,8 +63,7 @@ def test_lstm_fwd_bwd(dev, B, T, H, Din, bidir, persistent, monkeypatch):
         s.set_initial()
         seqs.append(s)
     engine.lstm_run_fwd(seqs, [P["weight_hh_l0" + sfx] for sfx, _ in dirs])
-    assert ops.lstm_timeout_word(dev, nseq, B, T, H) == 0
-    assert ops.lstm_sticky_timeouts() == 0
+    assert ops.lstm_sticky_timeouts() == 0 and ops.lstm_counters_at_rest(dev)
     for di, (s, (sfx, rev)) in enumerate(zip(seqs, dirs)):
         hout = s.hbuf[:, :T] if rev else s.hbuf[:, 1:]
         assert rel(hout, out[:, :, di * H:(di + 1) * H]) < TOL
@@ -76,8 +75,7 @@ def test_lstm_fwd_bwd(dev, B, T, H, Din, bidir, persistent, monkeypatch):
         exts.append((e, T * H, H))
         dcs.append(w_c[di].float().contiguous().to(dev))
     dgs = engine.lstm_run_bwd(seqs, [P["weight_hh_l0" + sfx] for sfx, _ in dirs], exts, [None] * len(dirs), dcs)
-    assert ops.lstm_timeout_word(dev, nseq, B, T, H) == 0
-    assert ops.lstm_sticky_timeouts() == 0
+    assert ops.lstm_sticky_timeouts() == 0 and ops.lstm_counters_at_rest(dev)
     dx = torch.zeros(B * T, Din, device=dev)
     for di, (s, (sfx, rev)) in enumerate(zip(seqs, dirs)):
         G = {k: torch.full_like(P[k + sfx], float("nan")) for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0",
@@ -88,6 +86,51 @@ def test_lstm_fwd_bwd(dev, B, T, H, Din, bidir, persistent, monkeypatch):
         for k, g in G.items():
             assert rel(g, dict(ref.named_parameters())[k + sfx].grad) < TOL, k + sfx
     assert rel(dx.view(B, T, Din), x.grad) < TOL
+
+
+@pytest.mark.parametrize("B,T,H,bidir", [(64, 6, 512, True), (256, 4, 1024, True), (256, 5, 512, False),
+                                          (200, 3, 1024, False)])
+def test_persistent_lstm_with_the_sticky_word_set_drains_and_recovers(dev, B, T, H, bidir):
+    """The fail-stop protocol of the persistent launches (include/cgn_hip.h), at plain and ROW-TILED shapes (RT 1, 4, 2,
+    4): with the sticky timeout word set every wait gives up within 64 polls, so the launch drains at once (its results
+    are invalid), it still leaves every arrival / exit counter at zero, and after the caller has cleared the word the
+    same launch gives the correct result again, bit for bit."""
+    engine, ops = _mods()
+    nseq = 2 if bidir else 1
+    assert ops.lstm_persistent_group(nseq, B, T, H, dev) > 0
+    g = torch.Generator().manual_seed(B + H)
+    seqs, whh = [], []
+    for i in range(nseq):
+        s = engine.LstmSeq(B, T, H, dev, bool(i))
+        s.xg.copy_(torch.randn(B, T, 4 * H, generator=g))
+        s.set_initial()
+        seqs.append(s)
+        whh.append((torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dev))
+    engine.lstm_run_fwd(seqs, whh)
+    assert ops.lstm_sticky_timeouts() == 0 and ops.lstm_counters_at_rest(dev)
+    good = [(s.hbuf.clone(), s.cbuf.clone(), s.gates.clone()) for s in seqs]
+    dcs = [torch.randn(B, H, generator=g).to(dev) for _ in seqs]
+    exts = [(torch.randn(B, T, H, generator=g).to(dev), T * H, H) for _ in seqs]
+    good_dg = [d.clone() for d in engine.lstm_run_bwd(seqs, whh, exts, [None] * nseq, [d.clone() for d in dcs])]
+    assert ops.lstm_sticky_timeouts() == 0 and ops.lstm_counters_at_rest(dev)
+    try:
+        for ws in ops._lstm_sync.values():
+            ws[-32] = 1
+        for s in seqs:
+            s.hbuf.fill_(float("nan"))
+        engine.lstm_run_fwd(seqs, whh)
+        engine.lstm_run_bwd(seqs, whh, exts, [None] * nseq, [d.clone() for d in dcs])
+        torch.cuda.synchronize()  # returns: the grid drained although no hand-off completed
+        assert ops.lstm_sticky_timeouts() > 0 and ops.lstm_counters_at_rest(dev)
+    finally:
+        ops.clear_lstm_sticky_timeouts()
+    engine.lstm_run_fwd(seqs, whh)
+    for s, (h, c, gt) in zip(seqs, good):
+        assert torch.equal(s.hbuf, h) and torch.equal(s.cbuf, c) and torch.equal(s.gates, gt)
+    again = engine.lstm_run_bwd(seqs, whh, exts, [None] * nseq, [d.clone() for d in dcs])
+    for a, b in zip(again, good_dg):
+        assert torch.equal(a, b)
+    assert ops.lstm_sticky_timeouts() == 0 and ops.lstm_counters_at_rest(dev)
 
 
 @pytest.mark.parametrize("B,T,H,Din", [(5, 4, 16, 12), (64, 21, 512, 24), (32, 16, 256, 20), (33, 7, 48, 9),
@@ -113,7 +156,7 @@ def test_lstm2_wavefront_fwd_bwd(dev, B, T, H, Din):
         s_.hbuf.fill_(float("nan")), s_.cbuf.fill_(float("nan")), s_.gates.fill_(float("nan"))
     ops.lstm2_fwd(g0.xg, None, P["weight_hh_l0"], P["weight_ih_l1"], P["weight_hh_l1"], P["bias_ih_l1"],
                   P["bias_hh_l1"], g0.hbuf, g0.cbuf, g0.gates, g1.hbuf, g1.cbuf, g1.gates, B, T, H)
-    assert ops.lstm_sticky_timeouts() == 0
+    assert ops.lstm_sticky_timeouts() == 0 and ops.lstm_counters_at_rest(dev)
     assert rel(g1.hbuf[:, 1:], out) < TOL
     for l, s_ in enumerate((g0, g1)):
         assert rel(s_.h_final(), h_n[l]) < TOL and rel(s_.c_final(), c_n[l]) < TOL
@@ -123,7 +166,7 @@ def test_lstm2_wavefront_fwd_bwd(dev, B, T, H, Din):
     dg1 = torch.full((B, T, 4 * H), float("nan"), device=dev)
     ops.lstm2_bwd(P["weight_hh_l0"], P["weight_ih_l1"], P["weight_hh_l1"], g0.cbuf, g0.gates, g1.cbuf, g1.gates, ext,
                   T * H, H, dg0, dg1, B, T, H)
-    assert ops.lstm_sticky_timeouts() == 0
+    assert ops.lstm_sticky_timeouts() == 0 and ops.lstm_counters_at_rest(dev)
     h0, h0ax = g0.hout_operand()
     for l, (s_, dg, xop) in enumerate(((g0, dg0, (xd, engine.Axis(Din, 0, 0))), (g1, dg1, (h0, h0ax)))):
         G = {k: torch.full_like(P[k + "_l%d" % l], float("nan")) for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")}

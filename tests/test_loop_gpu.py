@@ -181,6 +181,8 @@ def test_timed_out_persistent_launch_stops_the_training_loop(dev, tmp_path):
     finally:
         ops.clear_lstm_sticky_timeouts()
     assert ops.lstm_sticky_timeouts() == 0
+    # the launches that ran while the word was set gave up at their first wait, and still left their counters at zero
+    assert ops.lstm_counters_at_rest(dev)
     train_functions.train_complete_model(model, handler, cfg, True, 0.3, None, None, "t", num_steps=1)
 
 

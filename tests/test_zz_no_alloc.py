@@ -27,7 +27,8 @@ def _inputs(nseq, B, T, H, seed, dev):
     return seqs
 
 
-def _run(entry, nseq, B, T, H, seqs, dev, sync=None, status=None):
+def _prepare(nseq, B, T, H, seqs, dev):
+    """Output buffers (poisoned) + the host-side descriptor array: every allocation happens HERE, before the call."""
     L, lib = _lib()
     arr = (L.LstmFwdSeq * nseq)()
     outs = []
@@ -40,14 +41,28 @@ def _run(entry, nseq, B, T, H, seqs, dev, sync=None, status=None):
         arr[i].hbuf, arr[i].cbuf, arr[i].gates = hbuf.data_ptr(), cbuf.data_ptr(), gates.data_ptr()
         arr[i].reverse, arr[i].init_zero = s["reverse"], 1
         outs.append((hbuf, cbuf, gates))
+    return arr, outs
+
+
+def _call(entry, arr, nseq, B, T, H, sync=None, status=None):
+    L, lib = _lib()
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     if entry == "noalloc":
-        rc = lib.cgn_lstm_seq_fwd_persistent_noalloc_f32(stream, arr, nseq, B, T, H,
-                                                         C.c_void_p(status.data_ptr() if status is not None else 0))
-    else:
-        rc = lib.cgn_lstm_seq_fwd_persistent_f32(stream, arr, nseq, B, T, H, C.c_void_p(sync.data_ptr()),
-                                                 sync.numel() * 4)
+        return lib.cgn_lstm_seq_fwd_persistent_noalloc_f32(stream, arr, nseq, B, T, H,
+                                                           C.c_void_p(status.data_ptr() if status is not None else 0))
+    return lib.cgn_lstm_seq_fwd_persistent_f32(stream, arr, nseq, B, T, H, C.c_void_p(sync.data_ptr()),
+                                               sync.numel() * 4)
+
+
+def _run(entry, nseq, B, T, H, seqs, dev, sync=None, status=None, check_no_alloc=False):
+    arr, outs = _prepare(nseq, B, T, H, seqs, dev)
     torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    reserved_before = torch.cuda.memory_reserved()
+    rc = _call(entry, arr, nseq, B, T, H, sync=sync, status=status)
+    torch.cuda.synchronize()
+    if check_no_alloc:  # neither the device's free memory nor torch's pool moved across the call
+        assert torch.cuda.mem_get_info()[0] == free_before and torch.cuda.memory_reserved() == reserved_before
     return rc, outs
 
 
@@ -61,15 +76,51 @@ def test_noalloc_entry_matches_existing_entry_twice(dev):
         sync = torch.zeros(need.value // 4 + 64, dtype=torch.int32, device=dev)
         seqs = _inputs(nseq, B, T, H, seed, dev)
         rc_ref, ref = _run("ws", nseq, B, T, H, seqs, dev, sync=sync)
-        free_before = torch.cuda.mem_get_info()[0]
-        rc_new, new = _run("noalloc", nseq, B, T, H, seqs, dev, status=status)
+        if seed == 1:  # the first call on a device resolves the array's address (module load): not part of the claim
+            _run("noalloc", nseq, B, T, H, seqs, dev, status=status)
+        rc_new, new = _run("noalloc", nseq, B, T, H, seqs, dev, status=status, check_no_alloc=True)
         assert rc_ref == 0 and rc_new == 0
         assert int(sync[-32].item()) == 0 and int(status.item()) == 0  # no bounded wait ran out in either launch
         for (h0, c0, g0), (h1, c1, g1) in zip(ref, new):
             for a, b, nm in ((h0, h1, "hbuf"), (c0, c1, "cbuf"), (g0, g1, "gates")):
                 assert not torch.isnan(b).any(), nm
                 assert torch.equal(a, b), (nm, nseq, B, T, H)  # same kernel, same summation order: bit-exact
-        del free_before
+
+
+def test_noalloc_entry_under_graph_capture(dev):
+    """What the entry point is for: issued while a stream is being captured (no allocation, no memset, ONE kernel node),
+    then replayed twice; each replay reproduces the caller-workspace entry bit for bit (the counters are back at zero
+    after every launch). The entry point must have been called once on the device OUTSIDE capture before (that call
+    resolves the array's address), as include/cgn_hip.h says."""
+    L, lib = _lib()
+    nseq, B, T, H = 2, 48, 9, 256
+    need = C.c_int64(0)
+    assert lib.cgn_lstm_persistent_query(nseq, B, T, H, C.byref(need)) == 0 and need.value > 0
+    sync = torch.zeros(need.value // 4 + 64, dtype=torch.int32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    seqs = _inputs(nseq, B, T, H, 5, dev)
+    rc_ref, ref = _run("ws", nseq, B, T, H, seqs, dev, sync=sync)
+    rc0, _ = _run("noalloc", nseq, B, T, H, seqs, dev, status=status)  # outside capture first
+    assert rc_ref == 0 and rc0 == 0
+    arr, outs = _prepare(nseq, B, T, H, seqs, dev)
+    g = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream(dev)
+    st.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(st):
+        g.capture_begin()
+        rc = _call("noalloc", arr, nseq, B, T, H, status=status)
+        g.capture_end()
+    assert rc == 0
+    torch.cuda.current_stream(dev).wait_stream(st)
+    for _ in range(2):
+        for t3 in outs:
+            for t_ in t3:
+                t_.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0
+        for (h0, c0, g0), (h1, c1, g1) in zip(ref, outs):
+            assert torch.equal(h0, h1) and torch.equal(c0, c1) and torch.equal(g0, g1)
 
 
 def test_noalloc_entry_rejects_what_it_cannot_hold(dev):
