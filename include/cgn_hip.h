@@ -384,6 +384,10 @@ int cgn_adam_f32(void* stream, float* p, const float* g, float* m, float* v, int
                  float grad_scale);
 /* counter[0] += 1 on the stream: advances a device-resident Adam step count inside a captured hipGraph. */
 int cgn_incr_i32(void* stream, int32_t* counter);
+/* Measurement aid (no counterpart in the reference): *slot = the device's constant-rate wall clock (wall_clock64, 100 MHz)
+ * at the moment `stream` reaches this point. Unlike HIP events it can be a node of a captured hipGraph, so it times the
+ * phases of an UN-profiled replay (tools/step_stamps.py; hip/ops.py STAMPS). */
+int cgn_stamp_u64(void* stream, uint64_t* slot);
 /* 2-class head (discriminator_sentiment.py:76-77 + losses of cgn.py:167-170,306,318-334,1118):
  * logits = (feat*mask)·Wᵀ + b; stats = {mean CE(y), mean entropy}; p1 = softmax[:,1];
  * dlogits = d(w_ce*CE + w_ent*entropy)/dlogits. mask, y, p1, dlogits, stats nullable. */

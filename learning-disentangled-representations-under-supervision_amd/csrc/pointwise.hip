@@ -605,6 +605,17 @@ extern "C" int cgn_incr_i32(void* stream, int32_t* counter) {
     return CGN_OK;
 }
 
+// Measurement aid: one lane writes the device's constant-rate wall clock into *slot when the stream reaches this point.
+// Works as a node of a captured hipGraph, which HIP events and rocprofv3's per-kernel trace do not (un-profiled replays).
+static __global__ void stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+
+extern "C" int cgn_stamp_u64(void* stream, uint64_t* slot) {
+    CGN_CHECK_ARG(slot != nullptr);
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, S_(stream), (unsigned long long*)slot);
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}
+
 extern "C" int cgn_disc_head_f32(void* stream, const float* feat, int64_t ldf, const float* mask, const float* W,
                                  const float* bias, const int64_t* y, int32_t B, int32_t F, float w_ce, float w_ent,
                                  float* logits, float* p1, float* dlogits, float* stats) {

@@ -130,6 +130,7 @@ PROTOTYPES = {
     "cgn_rowdot_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_ptr]),
     "cgn_adam_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_ptr, c_f32]),
     "cgn_incr_i32": (c_i32, [c_ptr, c_ptr]),
+    "cgn_stamp_u64": (c_i32, [c_ptr, c_ptr]),
     "cgn_disc_head_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_f32, c_f32, c_ptr,
                                   c_ptr, c_ptr, c_ptr]),
     "cgn_disc_head_bwd_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_f32, c_ptr, c_ptr,

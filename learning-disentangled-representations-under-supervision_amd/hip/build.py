@@ -2,7 +2,9 @@
 
 The shared library is a plain C-ABI object (include/cgn_hip.h); it links only against the HIP runtime.
 """
+import hashlib
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -21,17 +23,42 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _deps_mtime():
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    hdrs.append(os.path.join(os.path.dirname(PKG_DIR), "include", "cgn_hip.h"))
-    return max(os.path.getmtime(h) for h in hdrs)
+PUBLIC_HEADER = os.path.join(os.path.dirname(PKG_DIR), "include", "cgn_hip.h")
+GEMM_SECTION_END = "Temperature softmax + NLL"  # first words of the section that follows the GEMM declarations
 
 
-def _compile(src, force, hdr_mtime):
+def _code_only(text):
+    """Source text without comments and blank runs: documentation edits do not rebuild anything."""
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    return re.sub(r"\s+", " ", text)
+
+
+def _fingerprint(src):
+    """Hash of everything a translation unit is compiled from: its own text, the local headers it includes, the public
+    header (code only; the three GEMM units see only its GEMM section - they take ~7 minutes each to compile and use
+    nothing else of it) and the compiler flags."""
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    text = open(os.path.join(CSRC, src)).read()
+    h.update(text.encode())
+    for inc in sorted(set(re.findall(r'#include\s+"([\w.]+)"', text)) | {"common.h"}):
+        path = os.path.join(CSRC, inc)
+        if os.path.exists(path):
+            h.update(open(path).read().encode())
+    pub = open(PUBLIC_HEADER).read()
+    if src.startswith("gemm"):
+        # (the marker sits inside a comment: cut the raw text there, then drop the comments)
+        pub = pub[:pub.index(GEMM_SECTION_END)]
+    h.update(_code_only(pub).encode())
+    return h.hexdigest()
+
+
+def _compile(src, force):
     obj = os.path.join(OBJ_DIR, src[:-4] + ".o")
+    dep = obj + ".dep"
     path = os.path.join(CSRC, src)
-    if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(path)
-            and os.path.getmtime(obj) >= hdr_mtime):
+    fp = _fingerprint(src)
+    if not force and os.path.exists(obj) and os.path.exists(dep) and open(dep).read().strip() == fp:
         return obj, False
     cmd = [HIPCC] + FLAGS + ["-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -39,6 +66,8 @@ def _compile(src, force, hdr_mtime):
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
     if r.stderr.strip():
         sys.stderr.write(r.stderr)
+    with open(dep, "w") as f:
+        f.write(fp + "\n")
     return obj, True
 
 
@@ -46,9 +75,8 @@ def build(force=False, verbose=True):
     os.makedirs(LIB_DIR, exist_ok=True)
     os.makedirs(OBJ_DIR, exist_ok=True)
     srcs = _sources()
-    hdr_mtime = _deps_mtime()
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        results = list(ex.map(lambda s: _compile(s, force, hdr_mtime), srcs))
+        results = list(ex.map(lambda s: _compile(s, force), srcs))
     objs = [o for o, _ in results]
     rebuilt = any(c for _, c in results)
     if rebuilt or not os.path.exists(LIB_PATH):

@@ -133,6 +133,11 @@ def _span_ok(t, base_off, axes_extents):
     return 0 <= hi < nelem
 
 
+# Plan hint for products issued where the GPU is shared by several streams (hip/step.py sets it for the step's tail):
+# {"splitk": n, "tile": t} stand in for force_splitk / force_tile when the caller gives none. None = the library's plan.
+PLAN_HINT = None
+
+
 def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, bias1=None,
          a_m=None, a_k=None, b_k=None, b_n=None, a_exp=None, softmax_bwd=None, force_tile=0, force_splitk=0,
          dyn=None, compute=None, c_t=None, _desc_only=False):
@@ -219,6 +224,9 @@ def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, 
     ws = workspace(dev)
     d.workspace = _ptr(ws)
     d.workspace_bytes = ws.numel() * 4
+    if PLAN_HINT is not None and a_exp is None and softmax_bwd is None:
+        force_tile = force_tile or PLAN_HINT.get("tile", 0)
+        force_splitk = force_splitk or PLAN_HINT.get("splitk", 0)
     d.force_tile, d.force_splitk = force_tile, force_splitk
     d.dyn_scalars = _ptr(dyn)
     d.compute = COMPUTE if compute is None else (_lib.COMPUTE_BF16 if compute == "bf16" else _lib.COMPUTE_F32)
@@ -497,6 +505,23 @@ def rowdot(a, b, out):
     _req(a.shape == b.shape and out.is_contiguous() and out.numel() == a.shape[0], "rowdot shapes")
     _call("cgn_rowdot_f32", a.device, _ptr(a), lda, _ptr(b), ldb, a.shape[0], a.shape[1], _ptr(out))
     return out
+
+
+# Phase stamps (measurement aid, tools/step_stamps.py): while STAMPS is a dict {"buf": int64 device tensor, "names": []}
+# every stamp(name) call appends a 1-thread kernel that writes the device wall clock into the next slot when the CURRENT
+# stream gets there - also inside a captured graph, so an un-profiled replay can be timed phase by phase. None = no-op.
+STAMPS = None
+
+
+def stamp(name):
+    st = STAMPS
+    if st is None:
+        return
+    i = len(st["names"])
+    if i >= st["buf"].numel():
+        return
+    st["names"].append(name)
+    _call("cgn_stamp_u64", st["buf"].device, C.c_void_p(st["buf"].data_ptr() + 8 * i))
 
 
 def incr(counter):

@@ -21,6 +21,12 @@ from .arena import ParamArena
 
 LIN = Axis(1, 0, 0)
 
+# experiment knobs for the step's tail (where three streams share the GPU): CGN_TAIL_SPLITK / CGN_TAIL_TILE force the
+# plan of every product issued there; CGN_HW_DW_EARLY=1 forks the highway's dW products where their inputs are ready
+TAIL_HINT = {k: int(os.environ[e]) for k, e in (("splitk", "CGN_TAIL_SPLITK"), ("tile", "CGN_TAIL_TILE"))
+             if os.environ.get(e)}
+HW_DW_EARLY = os.environ.get("CGN_HW_DW_EARLY") == "1"
+
 
 def _new(shape, dev, dtype=torch.float32):
     return ops.alloc(shape, dev, dtype)
@@ -173,6 +179,15 @@ class CGNStep:
     def flush(self, only=None):
         """Fork the queued work now. only=k: just side stream k's share (the rest stays queued, and later() keeps
         queueing for the other streams until a flush without `only`)."""
+        prev_hint = ops.PLAN_HINT
+        if self.overlap and TAIL_HINT:
+            ops.PLAN_HINT = TAIL_HINT
+        try:
+            self._flush(only)
+        finally:
+            ops.PLAN_HINT = prev_hint
+
+    def _flush(self, only):
         todo = [(k, fn) for k, fn in self._deferred if only is None or k == only]
         self._deferred = [(k, fn) for k, fn in self._deferred if not (only is None or k == only)]
         if only is None:
@@ -361,6 +376,7 @@ class CGNStep:
         He, Z = cfg.encoder_rnn_size, cfg.latent_variable_size
         N = B * L
         hw_out, hw_saved = engine.highway_fwd(enc_in, self._hw_layers(P))
+        ops.stamp("M highway fwd done")
         sf, sr = engine.LstmSeq(B, L, He, self.dev, False), engine.LstmSeq(B, L, He, self.dev, True)
         for s, sfx in ((sf, ""), (sr, "_reverse")):
             ops.gemm(hw_out, P["encoder.rnn.weight_ih_l0" + sfx].t(), s.xg.view(N, 4 * He),
@@ -369,7 +385,9 @@ class CGNStep:
         # No exclusive() here: the only work that can still be running is the tail of the discriminator step / c inference
         # on side stream 0, a chain of kernels with 1-113 workgroups that fit beside the recurrence's 256 (measured: the
         # join cost 54 us per step, the chain's last ~80 us ran with the whole GPU waiting; beside the launch it is free).
+        ops.stamp("M encoder W_ih products done")
         engine.lstm_run_fwd([sf, sr], [P["encoder.rnn.weight_hh_l0"], P["encoder.rnn.weight_hh_l0_reverse"]])
+        ops.stamp("M encoder LSTM fwd done")
         ctx = _new((B, 2 * He), self.dev)
         ops.copy2d(sf.c_final(), ctx[:, :He])
         ops.copy2d(sr.c_final(), ctx[:, He:])
@@ -413,10 +431,14 @@ class CGNStep:
         self.exclusive()
         dgf, dgr = engine.lstm_run_bwd([sf, sr], [P["encoder.rnn.weight_hh_l0"], P["encoder.rnn.weight_hh_l0_reverse"]],
                                        [None, None], [None, None], [dcf, dcr])
+        if param_grads:
+            ops.stamp("M encoder LSTM bwd done")
         hw_out = es["hw_out"]
         Din = hw_out.shape[1]
         if param_grads:
             # parameter gradients leave the critical path (dX chain) when streams overlap
+            if ops.STAMPS is not None:
+                self.later(0, lambda: ops.stamp("S0 deferred work begins (encoder LSTM dW)"))
             for s, dg, sfx in ((sf, dgf, ""), (sr, dgr, "_reverse")):
                 self.later(0, lambda s=s, dg=dg, sfx=sfx: engine.lstm_param_grads(
                     s, dg, (hw_out, Axis(hw_out.stride(0), 0, 0)), G["encoder.rnn.weight_ih_l0" + sfx],
@@ -429,11 +451,18 @@ class CGNStep:
             staggered = self.overlap and not getattr(self.recorder, "parallel", False)
             self.flush(only=1 if staggered else None)
         dhw = ops.new2d(N, Din, self.dev)
+        if param_grads:
+            ops.stamp("M forked deferred work")
+            if self.overlap and TAIL_HINT:
+                ops.PLAN_HINT = TAIL_HINT  # from here to the end of the step every product shares the GPU
         for i, (dg, sfx) in enumerate(((dgf, ""), (dgr, "_reverse"))):
             ops.gemm(dg.view(N, 4 * He), P["encoder.rnn.weight_ih_l0" + sfx], dhw, beta=(0.0 if i == 0 else 1.0))
             if param_grads and i == 0:
+                if ops.STAMPS is not None:
+                    self.later(0, lambda: ops.stamp("S0 encoder LSTM dW done"))
                 self.flush()
-        if param_grads and self.overlap and not self.dp and getattr(self.recorder, "parallel", False):
+        if (param_grads and self.overlap and not self.dp and getattr(self.recorder, "parallel", False)
+                and not HW_DW_EARLY):
             self._deferring = True  # the highway's dW products wait for the end of the dX chain (one more branch graph)
         turn = [0]
 
@@ -483,13 +512,18 @@ class CGNStep:
                                            calc_z_loss=calc_z_loss)
             self.join(0, 1)
             return d_losses, c_box[0], eg_losses
+        ops.stamp("M step begin")
         with self.side(0):
+            ops.stamp("S0 disc step begin")
             d_losses = self.disc_train(opts["disc"], d["x_labelled"], d["y_labelled"], d["x_generated"],
                                        d["c_generated"], d.get("mask_labelled"), d.get("mask_generated"))
+            ops.stamp("S0 disc step done")
             c, _ = self.infer_c(d["enc_word"], d["c_uniform"])
+            ops.stamp("S0 c inferred")
         eg_losses = self.enc_gen_train((opts["enc"], opts["gen"]), d["enc_word"], d["enc_char"], d["dec_word"],
                                        d["target"], c, d["eps"], kld_coeff, temperature, calc_z_loss=calc_z_loss)
         self.join(0, 1)
+        ops.stamp("M step end")
         return d_losses, c, eg_losses
 
     # -------------------------------------------------------------------------------------------------------------
@@ -526,6 +560,7 @@ class CGNStep:
         tfeat, tsaved = engine.tdnn_fwd(enc_char.reshape(N, Wl), P["embedding.char_embed.weight"], tk)
         ops.copy2d(tfeat, enc_in[:, E:])
         _cap_sel(capture, "enc/tdnn", tsaved["arg"])
+        ops.stamp("M embedding + TDNN done")
         # ---- encode_for_z (cgn.py:83-103) + KLD (:1076) + [z,c] (:1080) ------------------------------------------
         es = self._encoder_fwd(enc_in, B, L)
         if capture is not None:
@@ -535,7 +570,9 @@ class CGNStep:
         zc, std, kld = _new((B, Z + C), dev), _new((B, Z), dev), _new((1,), dev)
         if callable(c_target):
             c_target = c_target()  # data-parallel wake_sleep(): reduce + apply the discriminator gradients, then infer c
+        ops.stamp("M mu|logvar done (waits for c now)")
         self.join(0)  # wake_sleep(): the discriminator step and c inference ran beside the encoder forward
+        ops.stamp("M joined c")
         cvec = c_target.reshape(B, C)
         ops.reparam_kld_fwd(mulv, eps, cvec, zc, std, kld)
         # ---- generator (model/generator.py:45-64) --------------------------------------------------------------
@@ -555,6 +592,7 @@ class CGNStep:
         g0.xg_extra = zg
         g0.set_initial()
         g1.set_initial()
+        ops.stamp("M generator input products done")
         self.exclusive()
         if fuse2:
             ops.lstm2_fwd(g0.xg, zg, P["generator.rnn.weight_hh_l0"], P["generator.rnn.weight_ih_l1"],
@@ -568,6 +606,7 @@ class CGNStep:
                      bias0=P["generator.rnn.bias_ih_l1"], bias1=P["generator.rnn.bias_hh_l1"])
             engine.lstm_run_fwd([g1], [P["generator.rnn.weight_hh_l1"]])
         h1, h1ax = g1.hout_operand()
+        ops.stamp("M generator LSTM fwd done")
         # bf16 mode: the logits-sized tensors (logits, dlogits and the transposed copy dW_fc reads) are HELD in bf16 when the
         # shapes allow 16-byte rows (ops.BF16_STORAGE; include/cgn_hip.h CGN_STORE_*): half the HBM bytes of the five
         # largest products' big operand. Everything else stays fp32.
@@ -578,7 +617,9 @@ class CGNStep:
         ops.gemm(h1, P["generator.fc.weight"].t(), logits, M=NT, K=Hg, a_m=h1ax, a_k=LIN, bias0=P["generator.fc.bias"])
         # ---- temperature softmax + CE (cgn.py:1086-1092) -------------------------------------------------------
         tgt = target.reshape(-1)
+        ops.stamp("M vocabulary projection done")
         lse, nll, ce = ops.softmax_nll_fwd(logits, tgt, inv_tau, dyn=self._dyn())
+        ops.stamp("M softmax/CE done")
         need_soft = use_disc or calc_z_loss
         # (a loss that this step does not compute reads as the engine's constant zero: no fill kernel on the critical path)
         c_loss = self._zero1
@@ -587,6 +628,7 @@ class CGNStep:
             # ---- soft embedding (cgn.py:1103-1108): softmax(logits/tau) @ E, probabilities formed in the A loader
             out_emb = _new((NT, E), dev)
             ops.gemm(logits, table, out_emb, a_exp=(inv_tau, lse), dyn=self._dyn())
+            ops.stamp("M soft embedding done")
             d_out_emb = _new((NT, E), dev)
             ops.fill(d_out_emb, 0.0)  # rows t = T-1 stay zero: out_embedding[:, :-1, :] (cgn.py:1108)
         if use_disc:
@@ -633,6 +675,7 @@ class CGNStep:
         if not train:
             return ce, kld, z_loss, c_loss, enc_loss, gen_loss
         # ---- backward through softmax/CE + soft embedding, fused, in place over the logits ----------------------
+        ops.stamp("M c-loss chain done")
         rowdot = _new((NT,), dev)
         dlogits_t = _new((V, NT), dev, torch.bfloat16) if store16 else None  # k-contiguous A operand of dW_fc
         if need_soft:
@@ -649,14 +692,18 @@ class CGNStep:
                      softmax_bwd=dict(logits=logits, lse=lse, rowdot=rowdot, target=tgt, inv_tau=inv_tau,
                                       ce_scale=79.0 * inv_tau / NT), dyn=self._dyn())
         dlogits = logits
+        ops.stamp("M dlogits done")
         dH1 = _new((NT, Hg), dev)
         ops.gemm(dlogits, P["generator.fc.weight"], dH1)
+        ops.stamp("M dH1 done")
         # Parameter gradients of the generator: needed by nothing before its Adam step. With streams overlapped they are
         # queued (later) and forked behind the encoder's LSTM backward, the step's last persistent launch (see
         # exclusive()); otherwise they run here.
         self.begin_defer(capture)
         dl_rows = dlogits_t if store16 else dlogits.t()  # A[v, (b,t)] of dW_fc = dlogits^T . h1
-        self.later(1, lambda: (ops.gemm(dl_rows, h1, G["generator.fc.weight"], N=Hg, K=NT, b_k=h1ax, b_n=LIN),
+        self.later(1, lambda: (ops.stamp("S1 deferred work begins (dW_fc)"),
+                               ops.gemm(dl_rows, h1, G["generator.fc.weight"], N=Hg, K=NT, b_k=h1ax, b_n=LIN),
+                               ops.stamp("S1 dW_fc done"),
                                ops.colsum(dlogits, G["generator.fc.bias"])))
         # ---- generator LSTM backward ---------------------------------------------------------------------------
         self.exclusive()
@@ -679,6 +726,7 @@ class CGNStep:
         self.later(1, lambda: engine.lstm_param_grads(g1, dg1, (h0, h0ax), G["generator.rnn.weight_ih_l1"],
                                                       G["generator.rnn.weight_hh_l1"], G["generator.rnn.bias_ih_l1"],
                                                       G["generator.rnn.bias_hh_l1"]))
+        ops.stamp("M generator LSTM bwd done")
         dWih0 = G["generator.rnn.weight_ih_l0"]
         dsum = _new((B, 4 * Hg), dev)
         ops.sum_time(dg0, dsum)
@@ -699,16 +747,21 @@ class CGNStep:
         elif not joint:
             # the generator's Adam step follows its gradients (cgn.py:1143); the encoder backward does not wait for it.
             # dzc above was the last read of a generator weight on the main stream.
-            self.later(1, lambda: self._optim_step(opts[1]))
+            self.later(1, lambda: (ops.stamp("S1 generator gradients done"), self._optim_step(opts[1]),
+                                   ops.stamp("S1 generator Adam done")))
         # ---- encoder backward (cgn.py:1145-1149): kld_coef*KLD + z_out.backward(g) ---------------------------------
         dmulv = _new((B, 2 * Z), dev)
         ops.reparam_kld_bwd(mulv, eps, dzc, float(kld_coeff) / B, dmulv, dyn=self._dyn(2))
         d_enc_in = self._encoder_bwd(es, dmulv, param_grads=True)
+        ops.stamp("M highway bwd (dX) done")
         dtf = _new((N, S), dev)
         ops.copy2d(d_enc_in[:, E:], dtf)
         engine.tdnn_bwd(tsaved, tk, dtf, self._tdnn_kernels(G), G["embedding.char_embed.weight"])
+        ops.stamp("M TDNN + char embedding bwd done")
+        ops.PLAN_HINT = None
         self.flush()  # (nothing is left unless the encoder backward ran without parameter gradients)
         self.join(0, 1)
+        ops.stamp("M joined side streams")
         if capture is not None:
             capture["enc_grads"] = {n: g.clone() for n, g in self.arenas["enc"].grads.items()}
         if self.dp:
