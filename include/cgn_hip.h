@@ -384,6 +384,81 @@ int cgn_adam_f32(void* stream, float* p, const float* g, float* m, float* v, int
                  float grad_scale);
 /* counter[0] += 1 on the stream: advances a device-resident Adam step count inside a captured hipGraph. */
 int cgn_incr_i32(void* stream, int32_t* counter);
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused launch-bound chains of the encoder/generator step (csrc/fused.hip). Each replaces a chain of tiny dependent
+ * kernels between two large products by ONE launch with one workgroup per sentence. `scratch`: caller-owned device
+ * words, (B + 1) * 4 bytes, zeroed ONCE by the caller (a ticket the last workgroup re-arms + one float per sentence for
+ * the fixed-order batch sums); launches sharing a scratch must not overlap.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* The code head: context = cat(c_n fwd, c_n bwd) (model/encoder.py:40-46) -> mu | logvar (model/cgn.py:91-92, weights
+ * stacked [2Z, 2He]) -> z = eps * exp(0.5 logvar) + mu, std (cgn.py:94-101) -> KLD (cgn.py:1076) -> [z, c] (cgn.py:1078-
+ * 1080) -> zg = [z,c] . W_ih_l0[:, E:]^T, the tiled input's share of the generator's layer-0 gates (model/generator.py:
+ * 54-56, once per sentence instead of per token). Limits: 2He <= 2048, Z <= 128, Z + C <= 140, He % 2 == 0, ldw2 % 4 ==
+ * 0, ldzc % 4 == 0, W2 / Wzc 16-byte aligned and rows readable up to the next multiple of 4 columns. */
+typedef struct cgn_code_head_fwd {
+    const float* cf;   /* final cell state, forward sequence: element (b, j) at cf[b * ldc + j] */
+    const float* cr;   /* final cell state, reverse sequence, same addressing */
+    int64_t ldc;
+    const float* W2;   /* [2Z, 2He], row stride ldw2 */
+    int64_t ldw2;
+    const float* b2;   /* [2Z] */
+    const float* eps;  /* [B, Z] */
+    const float* c;    /* [B, C] (nullable when C == 0) */
+    const float* Wzc;  /* nullable: 4Hg rows of Z + C weights, row stride ldzc */
+    int64_t ldzc;
+    float* ctx;        /* [B, 2He] out */
+    float* mulv;       /* [B, 2Z] out */
+    float* zc;         /* [B, Z + C] out */
+    float* stdv;       /* [B, Z] out */
+    float* kld;        /* [1] out */
+    float* zg;         /* [B, G4] out (with Wzc) */
+    void* scratch;
+    int64_t scratch_bytes;
+    int32_t B, He, Z, C, G4;
+} cgn_code_head_fwd;
+int cgn_code_head_fwd_f32(void* stream, const cgn_code_head_fwd* d /* host */);
+
+/* Its backward (cgn.py:1099, :1142-1148): dsum = sum_t dgates0[:, t, :]; d[z,c] = dsum . W_ih_l0[:, E:] (its first Z
+ * columns are g = d(79 CE + recon)/dz); d[mu|logvar] through the reparametrisation plus the KLD term's own gradient
+ * (weight kld_w = kld_coef / B, or *dyn_kld_w); d(context) = d[mu|logvar] . W2, written as the two final cell states'
+ * gradients. Limits: G4 <= 4096, Z <= 128, Z + C <= 144. */
+typedef struct cgn_code_head_bwd {
+    const float* dg0;       /* [B, T, G4] */
+    const float* Wzc;
+    int64_t ldzc;
+    const float* mulv;      /* [B, 2Z] */
+    const float* eps;       /* [B, Z] */
+    const float* dyn_kld_w; /* device, nullable: overrides kld_w */
+    const float* W2;
+    int64_t ldw2;
+    float* dsum;            /* [B, G4] out */
+    float* dzc;             /* [B, Z + C] out */
+    float* dmulv;           /* [B, 2Z] out */
+    float* dcf;             /* [B, He] out */
+    float* dcr;             /* [B, He] out */
+    float kld_w;
+    int32_t B, T, He, Z, C, G4;
+} cgn_code_head_bwd;
+int cgn_code_head_bwd_f32(void* stream, const cgn_code_head_bwd* d /* host */);
+
+/* The c-reconstruction head behind the frozen text-CNN's convolution products (cgn.py:1114-1118 with
+ * discriminator_sentiment.py:66-77 in eval mode): ReLU + max over time with argmax, fc1, CE against c.long(), and the
+ * way back: dlogits = w_ce / B * (softmax - onehot), through fc1 and the pooling into dconv[i] (same shape as conv[i]:
+ * the gradient at each map's kept position, zeros elsewhere). conv[i] / dconv[i]: [B * P[i], Co[i]]; c: label b at
+ * c[b * ldc]; feat / arg [B, F = sum Co] out; stats[0] = mean CE. F <= 1024. */
+int cgn_textcnn_head_f32(void* stream, int32_t n, const float* const* conv /* host array */,
+                         float* const* dconv /* host array */, const int32_t* P /* host */, const int32_t* Co /* host */,
+                         int32_t B, const float* W, const float* bias, const float* c, int64_t ldc, float w_ce,
+                         float* feat, int32_t* arg, float* stats, void* scratch, int64_t scratch_bytes);
+
+/* cgn_conv_col2im_f32 for the soft embedding's gradient [B, T, E] (contiguous rows (b, t)): rows t < L receive the
+ * summed windows (+ beta * dx), rows L <= t < T zero (+ beta * dx): the dropped last timestep of cgn.py:1108; and
+ * rowdot[b*T + t] = sum_e dx[.., e] * other[(b*T + t) * ldo + e], the row dot product of the softmax Jacobian that the
+ * CGN_EPI_SOFTMAX_BWD epilogue reads (cgn.py:1103-1106 backwards). */
+int cgn_conv_col2im_rowdot_f32(void* stream, int32_t n, const float* const* dcols /* host array */,
+                               const int32_t* K /* host */, int32_t B, int32_t L, int32_t T, int32_t E, float beta,
+                               float* dx, const float* other, int64_t ldo, float* rowdot);
+
 /* Measurement aid (no counterpart in the reference): *slot = the device's constant-rate wall clock (wall_clock64, 100 MHz)
  * at the moment `stream` reaches this point. Unlike HIP events it can be a node of a captured hipGraph, so it times the
  * phases of an UN-profiled replay (tools/step_stamps.py; hip/ops.py STAMPS). */

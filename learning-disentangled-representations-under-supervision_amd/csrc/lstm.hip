@@ -364,9 +364,71 @@ __device__ __forceinline__ void st_sc1(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword ... sc1
 }
 
-// CPW: chunks (of 16 k) per wave held in registers; H <= 128 * CPW.
-template <int CPW>
+// ------------------------------------------------------------------------------------------------------------------
+// X6: the recurrent products on the bf16 matrix cores at fp32 accuracy.
+// A step's product is MFMA-paced at B = 64 (16 x 64 x H MACs per workgroup on the fp32 MFMA = 1.7 us at H = 512, a
+// third of the step), and gfx950's bf16 MFMA has 16x the fp32 rate. Every fp32 operand is split EXACTLY into three bf16
+// parts, x = p0 + p1 + p2 (8 + 8 + 8 significant bits: p0 = bf16(x), p1 = bf16(x - p0), p2 = x - p0 - p1; the two
+// subtractions are exact in fp32), and a.b is accumulated in fp32 from the six partial products of weight >= 2^-16:
+//   a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0      (dropped: a1b2, a2b1, a2b2 <= 2^-24 |a||b|, below fp32's own rounding)
+// = 6 v_mfma_f32_16x16x32_bf16 (16 cycles each per SIMD) for 32 k against 8 v_mfma_f32_16x16x4_f32 (32 cycles each):
+// 2.7x less MFMA time, same result to fp32 rounding (tests/test_kernels_gpu.py holds both forms to nn.LSTM in fp64 at
+// 1e-5). The weight slices are split once per launch (they live in registers as three bf16x8 per 8 k instead of two
+// f32x4: 1.5x the registers), h_t / dgates_t after each hand-off load. A lane's 8 k of a 32-k step are the quads of
+// TWO neighbouring 16-k chunks (any assignment of k to the MFMA's k slots is legal as long as A and B agree).
+// Which kernels use it: lstm_x6() / lstm_x6_bwd() below.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+struct Frag3 {
+    bf16x8_t p0, p1, p2;
+};
+__device__ __forceinline__ Frag3 split3(const f32x4& u, const f32x4& v) {
+    Frag3 f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float x = i < 4 ? u[i] : v[i - 4];
+        const __bf16 a = (__bf16)x;
+        const float r1 = x - (float)a;
+        const __bf16 b = (__bf16)r1;
+        const float r2 = r1 - (float)b;
+        f.p0[i] = a;
+        f.p1[i] = b;
+        f.p2[i] = (__bf16)r2;
+    }
+    return f;
+}
+#define CGN_MFMA_BF16(A_, B_, C_) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A_), (B_), (C_), 0, 0, 0)
+// NG accumulators that share the A operand (the four gates): term-major, so consecutive MFMAs are independent
+template <int NG>
+__device__ __forceinline__ void mfma_x6(const Frag3& a, const Frag3 (&b)[NG], f32x4 (&acc)[NG]) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = CGN_MFMA_BF16(a.p0, b[g].p2, acc[g]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = CGN_MFMA_BF16(a.p2, b[g].p0, acc[g]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = CGN_MFMA_BF16(a.p1, b[g].p1, acc[g]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = CGN_MFMA_BF16(a.p0, b[g].p1, acc[g]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = CGN_MFMA_BF16(a.p1, b[g].p0, acc[g]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = CGN_MFMA_BF16(a.p0, b[g].p0, acc[g]);
+}
+// one accumulator chain (backward kernels: two chains, even / odd chunk pairs)
+__device__ __forceinline__ f32x4 mfma_x6(const Frag3& a, const Frag3& b, f32x4 acc) {
+    acc = CGN_MFMA_BF16(a.p0, b.p2, acc);
+    acc = CGN_MFMA_BF16(a.p2, b.p0, acc);
+    acc = CGN_MFMA_BF16(a.p1, b.p1, acc);
+    acc = CGN_MFMA_BF16(a.p0, b.p1, acc);
+    acc = CGN_MFMA_BF16(a.p1, b.p0, acc);
+    acc = CGN_MFMA_BF16(a.p0, b.p0, acc);
+    return acc;
+}
+
+// CPW: chunks (of 16 k) per wave held in registers; H <= 128 * CPW. X6: see above.
+template <int CPW, bool X6>
 __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_kernel(const FwdParams p, unsigned* sync, unsigned* sticky) {
+    static_assert(CPW % 2 == 0, "X6 pairs neighbouring chunks");
     __shared__ float red[LSTM_NW][16][64];
     __shared__ int s_ok;
     const int B = p.B, T = p.T, H = p.H;
@@ -386,18 +448,36 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_kernel(const FwdPara
     // this workgroup's W_hh rows (4 gates x 16 units), this wave's k range: registers for the whole sequence
     const float* wrow = sq.w_hh + (long)(j0 + fr) * H;
     const long gate_stride = (long)H * H;
-    f32x4 w[4][CPW];
+    f32x4 w[X6 ? 1 : 4][X6 ? 1 : CPW];
+    Frag3 w3[X6 ? CPW / 2 : 1][X6 ? 4 : 1];  // [chunk pair][gate]
     int koff[CPW];
 #pragma unroll
     for (int u = 0; u < CPW; ++u) {
         const bool ok = (u < cpw) && (c_beg + u < nchunks);
         const int kc = ok ? (c_beg + u) * 16 + q * 4 : 0;
         koff[u] = kc * 4;
+    }
+#pragma unroll
+    for (int u = 0; u < CPW; u += 2) {
+        f32x4 v[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bool ok = (u + h < cpw) && (c_beg + u + h < nchunks);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 x = ld4(wrow + g * gate_stride + koff[u + h] / 4);
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                v[h][g] = ok ? x : z;
+            }
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 v = ld4(wrow + g * gate_stride + kc);
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            w[g][u] = ok ? v : z;
+            if constexpr (X6) {
+                w3[u / 2][g] = split3(v[0][g], v[1][g]);
+            } else {
+                w[g][u] = v[0][g];
+                w[g][u + 1] = v[1][g];
+            }
         }
     }
     const int bA = min(b0 + fr, B - 1);
@@ -450,13 +530,18 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_kernel(const FwdPara
             f32x4 a[CPW];
 #pragma unroll
             for (int u = 0; u < CPW; ++u) a[u] = ld4_sc1(hres, hoff + koff[u]);
+            if constexpr (X6) {
 #pragma unroll
-            for (int u = 0; u < CPW; ++u) {  // chunks beyond this wave's range hold zero weights: no branch
+                for (int u = 0; u < CPW; u += 2) mfma_x6<4>(split3(a[u], a[u + 1]), w3[u / 2], acc);
+            } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int u = 0; u < CPW; ++u) {  // chunks beyond this wave's range hold zero weights: no branch
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w[g][u][i], acc[g], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w[g][u][i], acc[g], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -498,8 +583,9 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_kernel(const FwdPara
 }
 
 // CPW: chunks (of 16 k over K = 4H) per wave held in registers; H <= 32 * CPW.
-template <int CPW>
+template <int CPW, bool X6>
 __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdParams p, unsigned* sync, unsigned* sticky) {
+    static_assert(CPW % 4 == 0, "two accumulator chains over chunk pairs");
     __shared__ float red[LSTM_NW][4][64];
     __shared__ int s_ok;
     const int B = p.B, T = p.T, H = p.H;
@@ -519,22 +605,32 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdPara
 
     // B operand = W_hhᵀ rows (j0 + fr), this wave's k range. Loaded once, so the untransposed [4H,H] weight serves as
     // well (16 lanes = 64 contiguous bytes per k) and the caller needs no transposed copy.
-    f32x4 w[CPW];
+    f32x4 w[X6 ? 1 : CPW];
+    Frag3 w3[X6 ? CPW / 2 : 1];
     int koff[CPW];
+    {
+        f32x4 prev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < CPW; ++u) {
-        const bool ok = (u < cpw) && (c_beg + u < nchunks);
-        const int kc = ok ? (c_beg + u) * 16 + q * 4 : 0;
-        koff[u] = kc * 4;
-        f32x4 v;
-        if (sq.w_hh) {
+        for (int u = 0; u < CPW; ++u) {
+            const bool ok = (u < cpw) && (c_beg + u < nchunks);
+            const int kc = ok ? (c_beg + u) * 16 + q * 4 : 0;
+            koff[u] = kc * 4;
+            f32x4 v;
+            if (sq.w_hh) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = sq.w_hh[(long)(kc + i) * H + j0 + fr];
-        } else {
-            v = ld4(sq.w_hh_t + (long)(j0 + fr) * K + kc);
+                for (int i = 0; i < 4; ++i) v[i] = sq.w_hh[(long)(kc + i) * H + j0 + fr];
+            } else {
+                v = ld4(sq.w_hh_t + (long)(j0 + fr) * K + kc);
+            }
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            v = ok ? v : z;
+            if constexpr (X6) {
+                if (u & 1) w3[u / 2] = split3(prev, v);
+                prev = v;
+            } else {
+                w[u] = v;
+            }
         }
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        w[u] = ok ? v : z;
     }
     const int bA = min(b0 + fr, B - 1);
     const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void*)sq.dgates, 0, B * T * K * 4, 0x00020000);
@@ -567,12 +663,20 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdPara
             f32x4 a[CPW];
 #pragma unroll
             for (int u = 0; u < CPW; ++u) a[u] = ld4_sc1(dres, aoff + koff[u]);
+            if constexpr (X6) {
 #pragma unroll
-            for (int u = 0; u < CPW; u += 2) {  // chunks beyond this wave's range hold zero weights: no branch
+                for (int u = 0; u < CPW; u += 4) {
+                    acc0 = mfma_x6(split3(a[u], a[u + 1]), w3[u / 2], acc0);
+                    acc1 = mfma_x6(split3(a[u + 2], a[u + 3]), w3[u / 2 + 1], acc1);
+                }
+            } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w[u][i], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u + 1][i], w[u + 1][i], acc1, 0, 0, 0);
+                for (int u = 0; u < CPW; u += 2) {  // chunks beyond this wave's range hold zero weights: no branch
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w[u][i], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u + 1][i], w[u + 1][i], acc1, 0, 0, 0);
+                    }
                 }
             }
         }
@@ -611,8 +715,9 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdPara
 // 32 KB reduction buffer; hand-off, counters and timeouts are those of the kernels above (one group = the workgroups
 // that share a 16RT-row batch tile). RT = 1, H <= 512 keeps the kernels above.
 // ------------------------------------------------------------------------------------------------------------------
-template <int CPW, int RT>
+template <int CPW, int RT, bool X6>
 __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdParams p, unsigned* sync, unsigned* sticky) {
+    static_assert(CPW % 2 == 0 && (!X6 || CPW <= 4), "X6: chunk pairs; the split weight slice of H = 1024 does not fit the registers");
     __shared__ float red[LSTM_NW][16][64];
     __shared__ int s_ok;
     const int B = p.B, T = p.T, H = p.H;
@@ -631,18 +736,36 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdP
 
     const float* wrow = sq.w_hh + (long)(j0 + fr) * H;
     const long gate_stride = (long)H * H;
-    f32x4 w[4][CPW];
+    f32x4 w[X6 ? 1 : 4][X6 ? 1 : CPW];
+    Frag3 w3[X6 ? CPW / 2 : 1][X6 ? 4 : 1];  // [chunk pair][gate]
     int koff[CPW];
 #pragma unroll
     for (int u = 0; u < CPW; ++u) {
         const bool ok = (u < cpw) && (c_beg + u < nchunks);
         const int kc = ok ? (c_beg + u) * 16 + q * 4 : 0;
         koff[u] = kc * 4;
+    }
+#pragma unroll
+    for (int u = 0; u < CPW; u += 2) {
+        f32x4 v[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bool ok = (u + h < cpw) && (c_beg + u + h < nchunks);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 x = ld4(wrow + g * gate_stride + koff[u + h] / 4);
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                v[h][g] = ok ? x : z;
+            }
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 v = ld4(wrow + g * gate_stride + kc);
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            w[g][u] = ok ? v : z;
+            if constexpr (X6) {
+                w3[u / 2][g] = split3(v[0][g], v[1][g]);
+            } else {
+                w[g][u] = v[0][g];
+                w[g][u + 1] = v[1][g];
+            }
         }
     }
     const __amdgpu_buffer_rsrc_t hres =
@@ -699,13 +822,18 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdP
                 f32x4 a[CPW];
 #pragma unroll
                 for (int u = 0; u < CPW; ++u) a[u] = ld4_sc1(hres, hoff + koff[u]);
+                if constexpr (X6) {
 #pragma unroll
-                for (int u = 0; u < CPW; ++u) {
+                    for (int u = 0; u < CPW; u += 2) mfma_x6<4>(split3(a[u], a[u + 1]), w3[u / 2], acc);
+                } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int u = 0; u < CPW; ++u) {
 #pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w[g][u][i], acc[g], 0, 0, 0);
+                        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+                                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w[g][u][i], acc[g], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -751,10 +879,11 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdP
 
 // CPW: chunks (of 16 k over K = 4H) per wave held in registers (H <= 32 * CPW); the gradient rows are loaded CB chunks at
 // a time (32 VGPRs) so that the 128-VGPR weight slice of H = 1024 leaves room for them.
-template <int CPW, int RT>
+template <int CPW, int RT, bool X6>
 __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_rt_kernel(const BwdParams p, unsigned* sync, unsigned* sticky) {
     constexpr int CB = CPW < 8 ? CPW : 8;
-    static_assert(CPW % CB == 0 && CB % 2 == 0, "chunk batches");
+    static_assert(CPW % CB == 0 && CB % 4 == 0, "chunk batches; two accumulator chains over chunk pairs");
+    static_assert(!X6 || CPW <= 16, "the split weight slice of H = 1024 does not fit the registers");
     __shared__ float red[LSTM_NW][4][64];
     __shared__ int s_ok;
     const int B = p.B, T = p.T, H = p.H;
@@ -772,10 +901,12 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_rt_kernel(const BwdP
     const int cpw = (nchunks + LSTM_NW - 1) / LSTM_NW;  // <= CPW (host check)
     const int c_beg = wave * cpw;
 
-    f32x4 w[CPW];
+    f32x4 w[X6 ? 1 : CPW];
+    Frag3 w3[X6 ? CPW / 2 : 1];
     int kbase;  // byte offset of this wave's first chunk + the lane's quad
     {
         kbase = (c_beg * 16 + q * 4) * 4;
+        f32x4 prev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < CPW; ++u) {
             const bool ok = (u < cpw) && (c_beg + u < nchunks);
@@ -788,7 +919,13 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_rt_kernel(const BwdP
                 v = ld4(sq.w_hh_t + (long)(j0 + fr) * K + kc);
             }
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            w[u] = ok ? v : z;
+            v = ok ? v : z;
+            if constexpr (X6) {
+                if (u & 1) w3[u / 2] = split3(prev, v);
+                prev = v;
+            } else {
+                w[u] = v;
+            }
         }
     }
     const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void*)sq.dgates, 0, B * T * K * 4, 0x00020000);
@@ -837,12 +974,20 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_rt_kernel(const BwdP
                         const int cu = (c0 + u < cpw && c_beg + c0 + u < nchunks) ? (c0 + u) : 0;
                         a[u] = ld4_sc1(dres, aoff + cu * 64);
                     }
+                    if constexpr (X6) {
 #pragma unroll
-                    for (int u = 0; u < CB; u += 2) {
+                        for (int u = 0; u < CB; u += 4) {
+                            acc0 = mfma_x6(split3(a[u], a[u + 1]), w3[(c0 + u) / 2], acc0);
+                            acc1 = mfma_x6(split3(a[u + 2], a[u + 3]), w3[(c0 + u) / 2 + 1], acc1);
+                        }
+                    } else {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w[c0 + u][i], acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u + 1][i], w[c0 + u + 1][i], acc1, 0, 0, 0);
+                        for (int u = 0; u < CB; u += 2) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w[c0 + u][i], acc0, 0, 0, 0);
+                                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u + 1][i], w[c0 + u + 1][i], acc1, 0, 0, 0);
+                            }
                         }
                     }
                 }
@@ -915,8 +1060,9 @@ struct Fwd2Params {
 // halves can run as two PHASES of a timestep: layer 0 runs ahead of layer 1, its h0_t has long arrived, and the
 // W_ih1·h0_t half is done while this group's own step t-1 is still being handed over; only the W_hh1·h1_{t-1} half
 // (the same work as a single-layer step) sits behind the own-group wait.
-template <int CPH>
+template <int CPH, bool X6>
 __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_fwd_kernel(const Fwd2Params p, unsigned* sync, unsigned* sticky) {
+    static_assert(CPH % 2 == 0, "X6 pairs neighbouring chunks");
     __shared__ float red[LSTM_NW][16][64];
     __shared__ int s_ok;
     const int B = p.B, T = p.T, H = p.H;
@@ -939,23 +1085,40 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_fwd_kernel(const Fwd2Pa
     auto chunk_ok = [&](int u) { return (u < cph) && (c_beg + u < nchunks); };
     auto colb = [&](int u) { return chunk_ok(u) ? (c_beg + u) * 16 : 0; };
 
-    f32x4 w_lo[4][CPH], w_hi[4][CPH];  // [gate][chunk]: W_ih1 (layer 1 only) and W_hh slices, resident for all T steps
+    // [gate][chunk]: W_ih1 (layer 1 only) and W_hh slices, resident for all T steps; X6: [chunk pair][gate] in bf16 parts
+    f32x4 w_lo[X6 ? 1 : 4][X6 ? 1 : CPH], w_hi[X6 ? 1 : 4][X6 ? 1 : CPH];
+    Frag3 w3_lo[X6 ? CPH / 2 : 1][X6 ? 4 : 1], w3_hi[X6 ? CPH / 2 : 1][X6 ? 4 : 1];
     {
         const float* w_own = layer ? p.w_hh1 : p.w_hh0;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < CPH; ++u) {
-            const bool ok = chunk_ok(u);
-            const long off = (long)(j0 + fr) * H + colb(u) + q * 4;
+        for (int u = 0; u < CPH; u += 2) {
+            f32x4 vh[2][4], vl[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bool ok = chunk_ok(u + h);
+                const long off = (long)(j0 + fr) * H + colb(u + h) + q * 4;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 xh = ld4(w_own + (long)g * H * H + off);
+                    vh[h][g] = ok ? xh : z;
+                    vl[h][g] = z;
+                    if (layer) {
+                        const f32x4 xl = ld4(p.w_ih1 + (long)g * H * H + off);
+                        vl[h][g] = ok ? xl : z;
+                    }
+                }
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 vh = ld4(w_own + (long)g * H * H + off);
-                w_hi[g][u] = ok ? vh : z;
-                if (layer) {
-                    const f32x4 vl = ld4(p.w_ih1 + (long)g * H * H + off);
-                    w_lo[g][u] = ok ? vl : z;
+                if constexpr (X6) {
+                    w3_hi[u / 2][g] = split3(vh[0][g], vh[1][g]);
+                    w3_lo[u / 2][g] = split3(vl[0][g], vl[1][g]);
                 } else {
-                    w_lo[g][u] = z;
+                    w_hi[g][u] = vh[0][g];
+                    w_hi[g][u + 1] = vh[1][g];
+                    w_lo[g][u] = vl[0][g];
+                    w_lo[g][u + 1] = vl[1][g];
                 }
             }
         }
@@ -1008,13 +1171,18 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_fwd_kernel(const Fwd2Pa
             f32x4 a[CPH];
 #pragma unroll
             for (int u = 0; u < CPH; ++u) a[u] = ld4_sc1(hres_below, off, colb(u) * 4);
+            if constexpr (X6) {
 #pragma unroll
-            for (int u = 0; u < CPH; ++u) {  // chunks beyond this wave's range hold zero weights: no branch
+                for (int u = 0; u < CPH; u += 2) mfma_x6<4>(split3(a[u], a[u + 1]), w3_lo[u / 2], acc);
+            } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int u = 0; u < CPH; ++u) {  // chunks beyond this wave's range hold zero weights: no branch
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w_lo[g][u][i], acc[g], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w_lo[g][u][i], acc[g], 0, 0, 0);
+                    }
                 }
             }
             __syncthreads();  // s_ok is rewritten below
@@ -1028,13 +1196,18 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_fwd_kernel(const Fwd2Pa
             f32x4 a[CPH];
 #pragma unroll
             for (int u = 0; u < CPH; ++u) a[u] = ld4_sc1(hres_own, off, colb(u) * 4);
+            if constexpr (X6) {
 #pragma unroll
-            for (int u = 0; u < CPH; ++u) {
+                for (int u = 0; u < CPH; u += 2) mfma_x6<4>(split3(a[u], a[u + 1]), w3_hi[u / 2], acc);
+            } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int u = 0; u < CPH; ++u) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w_hi[g][u][i], acc[g], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w_hi[g][u][i], acc[g], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -1093,8 +1266,10 @@ struct Bwd2Params {
 // dh0_t = W_ih1ᵀ·dg1_t + W_hh0ᵀ·dg0_{t+1}). CPH: chunks (of 16 k) per wave and per operand half held in registers:
 // 4H <= 128 * CPH. Two phases per timestep like the forward kernel: the W_ih1ᵀ·dg1_t half (the top layer runs ahead)
 // is done before this group's own previous step is waited for.
-template <int CPH>
+template <int CPH, bool X6>
 __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_bwd_kernel(const Bwd2Params p, unsigned* sync, unsigned* sticky) {
+    constexpr int CB = CPH < 8 ? CPH : 8;  // X6: the gradient rows are loaded CB chunks at a time (registers)
+    static_assert(CPH % CB == 0 && CB % 4 == 0, "chunk batches; two accumulator chains over chunk pairs");
     __shared__ float red[LSTM_NW][4][64];
     __shared__ int s_ok;
     const int B = p.B, T = p.T, H = p.H;
@@ -1118,10 +1293,12 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_bwd_kernel(const Bwd2Pa
 
     // B operands = rows (j0 + fr) of W_ih1ᵀ (bottom layer only) and of this layer's W_hhᵀ, read once from the
     // untransposed [4H,H] weights (16 lanes = 64 contiguous bytes per k)
-    f32x4 w_lo[CPH], w_hi[CPH];
+    f32x4 w_lo[X6 ? 1 : CPH], w_hi[X6 ? 1 : CPH];
+    Frag3 w3_lo[X6 ? CPH / 2 : 1], w3_hi[X6 ? CPH / 2 : 1];
     {
         const float* w_own = role ? p.w_hh0 : p.w_hh1;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 ph = z, pl = z;
 #pragma unroll
         for (int u = 0; u < CPH; ++u) {
             const bool ok = chunk_ok(u);
@@ -1133,8 +1310,19 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_bwd_kernel(const Bwd2Pa
 #pragma unroll
                 for (int i = 0; i < 4; ++i) vl[i] = p.w_ih1[(long)(col + i) * H + j0 + fr];
             }
-            w_hi[u] = ok ? vh : z;
-            w_lo[u] = ok ? vl : z;
+            vh = ok ? vh : z;
+            vl = ok ? vl : z;
+            if constexpr (X6) {
+                if (u & 1) {
+                    w3_hi[u / 2] = split3(ph, vh);
+                    w3_lo[u / 2] = split3(pl, vl);
+                }
+                ph = vh;
+                pl = vl;
+            } else {
+                w_hi[u] = vh;
+                w_lo[u] = vl;
+            }
         }
     }
     const int bA = min(b0 + fr, B - 1);
@@ -1167,15 +1355,29 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_bwd_kernel(const Bwd2Pa
             __syncthreads();
             if (!s_ok) break;  // workgroup-uniform
             const int off = (bA * T + t) * K4 * 4 + q * 16;
-            f32x4 a[CPH];
+            if constexpr (X6) {
 #pragma unroll
-            for (int u = 0; u < CPH; ++u) a[u] = ld4_sc1(dres_top, off, colb(u) * 4);
+                for (int c0 = 0; c0 < CPH; c0 += CB) {
+                    f32x4 a[CB];
 #pragma unroll
-            for (int u = 0; u < CPH; u += 2) {  // chunks beyond this wave's range hold zero weights: no branch
+                    for (int u = 0; u < CB; ++u) a[u] = ld4_sc1(dres_top, off, colb(c0 + u) * 4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w_lo[u][i], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u + 1][i], w_lo[u + 1][i], acc1, 0, 0, 0);
+                    for (int u = 0; u < CB; u += 4) {
+                        acc0 = mfma_x6(split3(a[u], a[u + 1]), w3_lo[(c0 + u) / 2], acc0);
+                        acc1 = mfma_x6(split3(a[u + 2], a[u + 3]), w3_lo[(c0 + u) / 2 + 1], acc1);
+                    }
+                }
+            } else {
+                f32x4 a[CPH];
+#pragma unroll
+                for (int u = 0; u < CPH; ++u) a[u] = ld4_sc1(dres_top, off, colb(u) * 4);
+#pragma unroll
+                for (int u = 0; u < CPH; u += 2) {  // chunks beyond this wave's range hold zero weights: no branch
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w_lo[u][i], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u + 1][i], w_lo[u + 1][i], acc1, 0, 0, 0);
+                    }
                 }
             }
             __syncthreads();  // s_ok is rewritten below
@@ -1186,15 +1388,29 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_bwd_kernel(const Bwd2Pa
             __syncthreads();
             if (!s_ok) break;  // workgroup-uniform
             const int off = (bA * T + t + 1) * K4 * 4 + q * 16;
-            f32x4 a[CPH];
+            if constexpr (X6) {
 #pragma unroll
-            for (int u = 0; u < CPH; ++u) a[u] = ld4_sc1(dres_own, off, colb(u) * 4);
+                for (int c0 = 0; c0 < CPH; c0 += CB) {
+                    f32x4 a[CB];
 #pragma unroll
-            for (int u = 0; u < CPH; u += 2) {
+                    for (int u = 0; u < CB; ++u) a[u] = ld4_sc1(dres_own, off, colb(c0 + u) * 4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w_hi[u][i], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u + 1][i], w_hi[u + 1][i], acc1, 0, 0, 0);
+                    for (int u = 0; u < CB; u += 4) {
+                        acc0 = mfma_x6(split3(a[u], a[u + 1]), w3_hi[(c0 + u) / 2], acc0);
+                        acc1 = mfma_x6(split3(a[u + 2], a[u + 3]), w3_hi[(c0 + u) / 2 + 1], acc1);
+                    }
+                }
+            } else {
+                f32x4 a[CPH];
+#pragma unroll
+                for (int u = 0; u < CPH; ++u) a[u] = ld4_sc1(dres_own, off, colb(u) * 4);
+#pragma unroll
+                for (int u = 0; u < CPH; u += 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w_hi[u][i], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u + 1][i], w_hi[u + 1][i], acc1, 0, 0, 0);
+                    }
                 }
             }
         }
@@ -1227,6 +1443,20 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_bwd_kernel(const Bwd2Pa
 int g_num_cus[16] = {0};
 
 // CGN_LSTM_XCD_MAP=0 keeps blockIdx order (hand-off groups spread over all XCDs) for A/B measurements
+// X6 (six bf16 partial products instead of the fp32 MFMA) is ON in the forward kernels and OFF in the backward ones:
+// measured at cfg2 (tools/lstm_bench.py, profiles/r03_lstm_bench.txt) forward 5.1 -> 4.5 us per step, two-layer forward
+// 7.5 -> 6.7; backward 6.0 -> 6.4 and 9.7 -> 11.5: a backward step hands over 4x the values (dgates, K = 4H), every
+// consumer wave splits its share again (64 values per lane and step: ~1 us of VALU work on a SIMD that two waves
+// share), which eats the MFMA time saved. (Splitting once at the producer and handing the bf16 parts over is the
+// next step.) CGN_LSTM_X6=0 / CGN_LSTM_X6_BWD=1 override (A/B measurements).
+bool lstm_x6() {
+    static const bool v = [] { const char* e = getenv("CGN_LSTM_X6"); return !(e && e[0] == '0'); }();
+    return v;
+}
+bool lstm_x6_bwd() {
+    static const bool v = [] { const char* e = getenv("CGN_LSTM_X6_BWD"); return e && e[0] == '1'; }();
+    return v;
+}
 int xcd_identity() {
     static const int v = [] { const char* e = getenv("CGN_LSTM_XCD_MAP"); return (e && e[0] == '0') ? 1 : 0; }();
     return v;
@@ -1389,19 +1619,22 @@ extern "C" int cgn_lstm_seq_fwd_persistent_f32(void* stream, const cgn_lstm_fwd_
     unsigned* sticky = (unsigned*)((char*)sync_ws + (sync_ws_bytes / 128 - 1) * 128);
     dim3 grid(nseq * cgn_cdiv(B, 16 * rt) * (H / 16));
     unsigned* sw = (unsigned*)sync_ws;
-#define CGN_FWD_RT(CPW, RT) hipLaunchKernelGGL((lstm_persist_fwd_rt_kernel<CPW, RT>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky)
-    if (rt == 1 && H <= 256)
-        hipLaunchKernelGGL((lstm_persist_fwd_kernel<2>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky);
-    else if (rt == 1 && H <= 512)
-        hipLaunchKernelGGL((lstm_persist_fwd_kernel<4>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky);
-    else if (rt == 1) CGN_FWD_RT(8, 1);
-    else if (rt == 2 && H <= 256) CGN_FWD_RT(2, 2);
-    else if (rt == 2 && H <= 512) CGN_FWD_RT(4, 2);
-    else if (rt == 2) CGN_FWD_RT(8, 2);
-    else if (H <= 256) CGN_FWD_RT(2, 4);
-    else if (H <= 512) CGN_FWD_RT(4, 4);
-    else CGN_FWD_RT(8, 4);
+    const bool x6 = lstm_x6();
+#define CGN_FWD_K(CPW) do { if (x6) hipLaunchKernelGGL((lstm_persist_fwd_kernel<CPW, true>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky); \
+                            else hipLaunchKernelGGL((lstm_persist_fwd_kernel<CPW, false>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky); } while (0)
+#define CGN_FWD_RT(CPW, RT, X) hipLaunchKernelGGL((lstm_persist_fwd_rt_kernel<CPW, RT, X>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky)
+#define CGN_FWD_RTX(CPW, RT) do { if (x6) CGN_FWD_RT(CPW, RT, true); else CGN_FWD_RT(CPW, RT, false); } while (0)
+    if (rt == 1 && H <= 256) CGN_FWD_K(2);
+    else if (rt == 1 && H <= 512) CGN_FWD_K(4);
+    else if (rt == 1) CGN_FWD_RT(8, 1, false);
+    else if (rt == 2 && H <= 256) CGN_FWD_RTX(2, 2);
+    else if (rt == 2 && H <= 512) CGN_FWD_RTX(4, 2);
+    else if (rt == 2) CGN_FWD_RT(8, 2, false);
+    else if (H <= 256) CGN_FWD_RTX(2, 4);
+    else if (H <= 512) CGN_FWD_RTX(4, 4);
+    else CGN_FWD_RT(8, 4, false);
 #undef CGN_FWD_RT
+#undef CGN_FWD_RTX
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }
@@ -1464,10 +1697,11 @@ extern "C" int cgn_lstm_seq_fwd_persistent_noalloc_f32(void* stream, const cgn_l
     // the counters are at zero: the array starts zeroed and every launch re-arms them on its way out (persist_checkout)
     unsigned* sticky = status ? status : scratch + (NOALLOC_LINES - 1) * SYNC_STRIDE;
     dim3 grid(nseq * cgn_cdiv(B, 16) * (H / 16));
-    if (H <= 256)
-        hipLaunchKernelGGL((lstm_persist_fwd_kernel<2>), grid, dim3(LSTM_NT), 0, st, p, scratch, sticky);
-    else
-        hipLaunchKernelGGL((lstm_persist_fwd_kernel<4>), grid, dim3(LSTM_NT), 0, st, p, scratch, sticky);
+    unsigned* sw = scratch;
+    const bool x6 = lstm_x6();
+    if (H <= 256) CGN_FWD_K(2);
+    else CGN_FWD_K(4);
+#undef CGN_FWD_K
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }
@@ -1494,19 +1728,23 @@ extern "C" int cgn_lstm_seq_bwd_persistent_f32(void* stream, const cgn_lstm_bwd_
     unsigned* sticky = (unsigned*)((char*)sync_ws + (sync_ws_bytes / 128 - 1) * 128);
     dim3 grid(nseq * cgn_cdiv(B, 16 * rt) * (H / 16));
     unsigned* sw = (unsigned*)sync_ws;
-#define CGN_BWD_RT(CPW, RT) hipLaunchKernelGGL((lstm_persist_bwd_rt_kernel<CPW, RT>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky)
-    if (rt == 1 && H <= 256)
-        hipLaunchKernelGGL((lstm_persist_bwd_kernel<8>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky);
-    else if (rt == 1 && H <= 512)
-        hipLaunchKernelGGL((lstm_persist_bwd_kernel<16>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky);
-    else if (rt == 1) CGN_BWD_RT(32, 1);
-    else if (rt == 2 && H <= 256) CGN_BWD_RT(8, 2);
-    else if (rt == 2 && H <= 512) CGN_BWD_RT(16, 2);
-    else if (rt == 2) CGN_BWD_RT(32, 2);
-    else if (H <= 256) CGN_BWD_RT(8, 4);
-    else if (H <= 512) CGN_BWD_RT(16, 4);
-    else CGN_BWD_RT(32, 4);
+    const bool x6 = lstm_x6_bwd();
+#define CGN_BWD_K(CPW) do { if (x6) hipLaunchKernelGGL((lstm_persist_bwd_kernel<CPW, true>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky); \
+                            else hipLaunchKernelGGL((lstm_persist_bwd_kernel<CPW, false>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky); } while (0)
+#define CGN_BWD_RT(CPW, RT, X) hipLaunchKernelGGL((lstm_persist_bwd_rt_kernel<CPW, RT, X>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky)
+#define CGN_BWD_RTX(CPW, RT) do { if (x6) CGN_BWD_RT(CPW, RT, true); else CGN_BWD_RT(CPW, RT, false); } while (0)
+    if (rt == 1 && H <= 256) CGN_BWD_K(8);
+    else if (rt == 1 && H <= 512) CGN_BWD_K(16);
+    else if (rt == 1) CGN_BWD_RT(32, 1, false);
+    else if (rt == 2 && H <= 256) CGN_BWD_RTX(8, 2);
+    else if (rt == 2 && H <= 512) CGN_BWD_RTX(16, 2);
+    else if (rt == 2) CGN_BWD_RT(32, 2, false);
+    else if (H <= 256) CGN_BWD_RTX(8, 4);
+    else if (H <= 512) CGN_BWD_RTX(16, 4);
+    else CGN_BWD_RT(32, 4, false);
+#undef CGN_BWD_K
 #undef CGN_BWD_RT
+#undef CGN_BWD_RTX
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }
@@ -1537,10 +1775,11 @@ extern "C" int cgn_lstm2_fwd_persistent_f32(void* stream, const cgn_lstm2_fwd* d
     hipStream_t st = (hipStream_t)stream;
     unsigned* sticky = (unsigned*)((char*)sync_ws + (sync_ws_bytes / 128 - 1) * 128);
     dim3 grid(2 * cgn_cdiv(B, 16) * (H / 16));
-    if (H <= 256)
-        hipLaunchKernelGGL((lstm2_persist_fwd_kernel<2>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws, sticky);
-    else
-        hipLaunchKernelGGL((lstm2_persist_fwd_kernel<4>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws, sticky);
+    unsigned* sw = (unsigned*)sync_ws;
+    if (H <= 256 && lstm_x6()) hipLaunchKernelGGL((lstm2_persist_fwd_kernel<2, true>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky);
+    else if (H <= 256) hipLaunchKernelGGL((lstm2_persist_fwd_kernel<2, false>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky);
+    else if (lstm_x6()) hipLaunchKernelGGL((lstm2_persist_fwd_kernel<4, true>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky);
+    else hipLaunchKernelGGL((lstm2_persist_fwd_kernel<4, false>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky);
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }
@@ -1564,10 +1803,11 @@ extern "C" int cgn_lstm2_bwd_persistent_f32(void* stream, const cgn_lstm2_bwd* d
     hipStream_t st = (hipStream_t)stream;
     unsigned* sticky = (unsigned*)((char*)sync_ws + (sync_ws_bytes / 128 - 1) * 128);
     dim3 grid(2 * cgn_cdiv(B, 16) * (H / 16));
-    if (H <= 256)
-        hipLaunchKernelGGL((lstm2_persist_bwd_kernel<8>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws, sticky);
-    else
-        hipLaunchKernelGGL((lstm2_persist_bwd_kernel<16>), grid, dim3(LSTM_NT), 0, st, p, (unsigned*)sync_ws, sticky);
+    unsigned* sw = (unsigned*)sync_ws;
+    if (H <= 256 && lstm_x6_bwd()) hipLaunchKernelGGL((lstm2_persist_bwd_kernel<8, true>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky);
+    else if (H <= 256) hipLaunchKernelGGL((lstm2_persist_bwd_kernel<8, false>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky);
+    else if (lstm_x6_bwd()) hipLaunchKernelGGL((lstm2_persist_bwd_kernel<16, true>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky);
+    else hipLaunchKernelGGL((lstm2_persist_bwd_kernel<16, false>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky);
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }

@@ -72,6 +72,20 @@ class Lstm2Bwd(C.Structure):
                                      "dgates0", "dgates1")] + [("dh_bs", c_i64), ("dh_ts", c_i64)]
 
 
+class CodeHeadFwd(C.Structure):
+    _fields_ = [("cf", c_ptr), ("cr", c_ptr), ("ldc", c_i64), ("W2", c_ptr), ("ldw2", c_i64), ("b2", c_ptr),
+                ("eps", c_ptr), ("c", c_ptr), ("Wzc", c_ptr), ("ldzc", c_i64), ("ctx", c_ptr), ("mulv", c_ptr),
+                ("zc", c_ptr), ("stdv", c_ptr), ("kld", c_ptr), ("zg", c_ptr), ("scratch", c_ptr),
+                ("scratch_bytes", c_i64), ("B", c_i32), ("He", c_i32), ("Z", c_i32), ("C", c_i32), ("G4", c_i32)]
+
+
+class CodeHeadBwd(C.Structure):
+    _fields_ = [("dg0", c_ptr), ("Wzc", c_ptr), ("ldzc", c_i64), ("mulv", c_ptr), ("eps", c_ptr), ("dyn_kld_w", c_ptr),
+                ("W2", c_ptr), ("ldw2", c_i64), ("dsum", c_ptr), ("dzc", c_ptr), ("dmulv", c_ptr), ("dcf", c_ptr),
+                ("dcr", c_ptr), ("kld_w", c_f32), ("B", c_i32), ("T", c_i32), ("He", c_i32), ("Z", c_i32), ("C", c_i32),
+                ("G4", c_i32)]
+
+
 class ConvWidths(C.Structure):
     _fields_ = [("W", c_ptr * 8), ("dW", c_ptr * 8), ("db", c_ptr * 8),
                 ("K", c_i32 * 8), ("Co", c_i32 * 8), ("col0", c_i32 * 8),
@@ -131,6 +145,13 @@ PROTOTYPES = {
     "cgn_adam_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_ptr, c_f32]),
     "cgn_incr_i32": (c_i32, [c_ptr, c_ptr]),
     "cgn_stamp_u64": (c_i32, [c_ptr, c_ptr]),
+    "cgn_code_head_fwd_f32": (c_i32, [c_ptr, C.POINTER(CodeHeadFwd)]),
+    "cgn_code_head_bwd_f32": (c_i32, [c_ptr, C.POINTER(CodeHeadBwd)]),
+    "cgn_textcnn_head_f32": (c_i32, [c_ptr, c_i32, C.POINTER(c_ptr), C.POINTER(c_ptr), C.POINTER(c_i32),
+                                     C.POINTER(c_i32), c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_ptr, c_ptr, c_ptr,
+                                     c_ptr, c_i64]),
+    "cgn_conv_col2im_rowdot_f32": (c_i32, [c_ptr, c_i32, C.POINTER(c_ptr), C.POINTER(c_i32), c_i32, c_i32, c_i32,
+                                           c_i32, c_f32, c_ptr, c_ptr, c_i64, c_ptr]),
     "cgn_disc_head_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_f32, c_f32, c_ptr,
                                   c_ptr, c_ptr, c_ptr]),
     "cgn_disc_head_bwd_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_f32, c_ptr, c_ptr,

@@ -272,6 +272,23 @@ def lstm_param_grads(seq, dgates, x_operand, dW_ih, dW_hh, db_ih, db_hh, beta=0.
 # ------------------------------------------------------------------------------------------------------------------
 # text-CNN discriminator (model/discriminator_sentiment.py:56-78)
 # ------------------------------------------------------------------------------------------------------------------
+def textcnn_conv_fwd(x, B, L, E, sent_stride, conv_w, conv_b):
+    """The convolution products only (all filter widths in one grouped launch): returns ([B*P_w, Co_w] per width, Ps)."""
+    dev = x.device
+    calls, convs, Ps = [], [], []
+    for w, b in zip(conv_w, conv_b):
+        Co, _, K, Ew = w.shape
+        if K > L:
+            raise RuntimeError("Kernel size can't be greater than actual input size (K=%d, L=%d)" % (K, L))
+        P = L - K + 1
+        conv = _new((B * P, Co), dev)
+        calls.append((x, w.view(Co, K * E).t(), conv, dict(M=B * P, K=K * E, a_m=Axis(E, P, sent_stride), a_k=LIN,
+                                                            bias0=b, compute="f32")))
+        convs.append(conv), Ps.append(P)
+    ops.gemm_group(calls)
+    return convs, Ps
+
+
 def textcnn_features_fwd(x, B, L, E, sent_stride, conv_w, conv_b, grouped=True):
     """x: tensor whose element (b,t,e) sits at b*sent_stride + t*E + e. Returns feat [B,F], arg [B,F]."""
     dev = x.device

@@ -507,6 +507,158 @@ def rowdot(a, b, out):
     return out
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# fused launch-bound chains (csrc/fused.hip)
+# ------------------------------------------------------------------------------------------------------------------
+FUSED_CHAINS = os.environ.get("CGN_FUSED_CHAINS", "1") != "0"  # 0: the round-2 chains of small kernels (A/B, fallback test)
+_fused_scratch = {}
+FUSED_SCRATCH_WORDS = 4096 + 64
+
+
+def _fused_scratch_ws(device):
+    """Ticket + per-sentence slots of the fused kernels' batch sums: zeroed once, one per (device, stream)."""
+    idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    ws = _fused_scratch.get(key)
+    if ws is None:
+        with torch.cuda.stream(torch.cuda.default_stream(idx)):
+            ws = torch.zeros(FUSED_SCRATCH_WORDS, dtype=torch.int32, device=torch.device("cuda", idx))
+        _fused_scratch[key] = ws
+    return ws
+
+
+def code_head_eligible(B, He, Z, Cc, w2, wzc):
+    """Shapes / layouts the fused code head takes (cgn_code_head_fwd/bwd_f32); else the unfused chain runs."""
+    return (FUSED_CHAINS and w2 is not None and 2 * He <= 2048 and He % 2 == 0 and Z <= 128 and Z + Cc <= 140
+            and B + 1 <= FUSED_SCRATCH_WORDS and w2.stride(1) == 1 and w2.stride(0) % 4 == 0 and w2.data_ptr() % 16 == 0
+            and (wzc is None or (wzc.stride(1) == 1 and wzc.stride(0) % 4 == 0 and wzc.data_ptr() % 16 == 0
+                                 and wzc.stride(0) >= pad4(Z + Cc) and wzc.shape[0] <= 4096)))
+
+
+def code_head_fwd(cf, cr, w2, b2, eps, c, wzc, ctx, mulv, zc, stdv, kld, zg):
+    """cf, cr: [B, He] final cell states (equal row strides); w2 [2Z, 2He] stacked mu|logvar weights; wzc: generator
+    W_ih_l0[:, E:] view [4Hg, Z+C] or None. Fills ctx, mulv, zc, stdv, kld (and zg). include/cgn_hip.h."""
+    B, He = cf.shape
+    Z = eps.shape[1]
+    Cc = zc.shape[1] - Z
+    for t, n in ((cf, "cf"), (cr, "cr"), (w2, "w2"), (b2, "b2"), (eps, "eps"), (ctx, "ctx"), (mulv, "mulv"), (zc, "zc"),
+                 (stdv, "stdv"), (kld, "kld")):
+        _chk_f32(t, n)
+    _req(cr.shape == cf.shape and cf.stride(1) == 1 and cr.stride(1) == 1 and cf.stride(0) == cr.stride(0),
+         "cf / cr must be [B, He] views with equal row strides")
+    _req(tuple(w2.shape) == (2 * Z, 2 * He) and b2.is_contiguous() and b2.numel() == 2 * Z, "w2 / b2 shapes")
+    _req(eps.is_contiguous() and eps.shape == (B, Z) and ctx.is_contiguous() and ctx.shape == (B, 2 * He)
+         and mulv.is_contiguous() and mulv.shape == (B, 2 * Z) and zc.is_contiguous() and zc.shape[0] == B
+         and stdv.is_contiguous() and stdv.shape == (B, Z) and kld.numel() == 1, "code_head_fwd shapes")
+    _req(code_head_eligible(B, He, Z, Cc, w2, wzc), "shape not eligible for the fused code head")
+    d = _lib.CodeHeadFwd()
+    d.cf, d.cr, d.ldc = cf.data_ptr(), cr.data_ptr(), cf.stride(0)
+    d.W2, d.ldw2, d.b2, d.eps = w2.data_ptr(), w2.stride(0), b2.data_ptr(), eps.data_ptr()
+    if Cc > 0:
+        _chk_f32(c, "c")
+        _req(c.is_contiguous() and c.numel() == B * Cc, "c must be [B, C]")
+        d.c = c.data_ptr()
+    if wzc is not None:
+        _chk_f32(wzc, "wzc"), _chk_f32(zg, "zg")
+        G4 = wzc.shape[0]
+        _req(wzc.shape[1] == Z + Cc and zg.is_contiguous() and zg.shape == (B, G4), "wzc / zg shapes")
+        # the kernel reads whole 16-byte quads of a weight row: the last row's pad columns must lie inside the storage
+        nelem = wzc.untyped_storage().nbytes() // 4 - wzc.storage_offset()
+        _req((G4 - 1) * wzc.stride(0) + pad4(Z + Cc) <= nelem, "wzc rows must be readable up to a multiple of 4 columns")
+        d.Wzc, d.ldzc, d.zg, d.G4 = wzc.data_ptr(), wzc.stride(0), zg.data_ptr(), G4
+    d.ctx, d.mulv, d.zc, d.stdv, d.kld = ctx.data_ptr(), mulv.data_ptr(), zc.data_ptr(), stdv.data_ptr(), kld.data_ptr()
+    ws = _fused_scratch_ws(cf.device)
+    d.scratch, d.scratch_bytes = ws.data_ptr(), ws.numel() * 4
+    d.B, d.He, d.Z, d.C = B, He, Z, Cc
+    _call("cgn_code_head_fwd_f32", cf.device, C.byref(d))
+
+
+def code_head_bwd(dg0, wzc, mulv, eps, w2, kld_weight, dsum, dzc, dmulv, dcf, dcr, dyn=None):
+    """Backward of code_head_fwd from the generator's layer-0 gate gradients dg0 [B, T, 4Hg]. include/cgn_hip.h."""
+    B, T, G4 = dg0.shape
+    Z = eps.shape[1]
+    Cc = dzc.shape[1] - Z
+    He = dcf.shape[1]
+    for t, n in ((dg0, "dg0"), (wzc, "wzc"), (mulv, "mulv"), (eps, "eps"), (w2, "w2"), (dsum, "dsum"), (dzc, "dzc"),
+                 (dmulv, "dmulv"), (dcf, "dcf"), (dcr, "dcr")):
+        _chk_f32(t, n)
+    for t, n in ((dg0, "dg0"), (mulv, "mulv"), (eps, "eps"), (dsum, "dsum"), (dzc, "dzc"), (dmulv, "dmulv"), (dcf, "dcf"),
+                 (dcr, "dcr")):
+        _req(t.is_contiguous(), n + " must be contiguous")
+    _req(tuple(wzc.shape) == (G4, Z + Cc) and wzc.stride(1) == 1 and tuple(w2.shape) == (2 * Z, 2 * He)
+         and w2.stride(1) == 1 and mulv.shape == (B, 2 * Z) and eps.shape == (B, Z) and dsum.shape == (B, G4)
+         and dzc.shape[0] == B and dmulv.shape == (B, 2 * Z) and dcf.shape == (B, He) and dcr.shape == (B, He),
+         "code_head_bwd shapes")
+    _req(G4 <= 4096 and Z <= 128 and Z + Cc <= 144, "shape not eligible for the fused code head backward")
+    d = _lib.CodeHeadBwd()
+    d.dg0, d.Wzc, d.ldzc, d.mulv, d.eps = dg0.data_ptr(), wzc.data_ptr(), wzc.stride(0), mulv.data_ptr(), eps.data_ptr()
+    d.dyn_kld_w = dyn.data_ptr() if dyn is not None else None
+    d.W2, d.ldw2 = w2.data_ptr(), w2.stride(0)
+    d.dsum, d.dzc, d.dmulv, d.dcf, d.dcr = dsum.data_ptr(), dzc.data_ptr(), dmulv.data_ptr(), dcf.data_ptr(), dcr.data_ptr()
+    d.kld_w = float(kld_weight)
+    d.B, d.T, d.He, d.Z, d.C, d.G4 = B, T, He, Z, Cc, G4
+    _call("cgn_code_head_bwd_f32", dg0.device, C.byref(d))
+
+
+def textcnn_head(convs, Ps, B, W, bias, c, w_ce, feat, arg, stats):
+    """ReLU + max over time + fc1 + CE(c.long()) + the way back into dconv matrices, one launch (cgn_textcnn_head_f32).
+    convs[i]: [B*Ps[i], Co_i] contiguous; c: [B] float view (any stride). Returns the list of dconv matrices."""
+    n = len(convs)
+    _req(1 <= n <= 8 and len(Ps) == n, "1..8 widths")
+    F = sum(cv.shape[1] for cv in convs)
+    _chk_f32(W, "W"), _chk_f32(bias, "bias"), _chk_f32(c, "c"), _chk_f32(feat, "feat"), _chk_f32(stats, "stats")
+    _req(W.is_contiguous() and W.shape == (2, F) and bias.numel() == 2 and c.dim() == 1 and c.numel() == B
+         and feat.is_contiguous() and feat.shape == (B, F) and arg.is_cuda and arg.dtype == torch.int32
+         and arg.is_contiguous() and arg.shape == (B, F) and stats.is_contiguous() and stats.numel() >= 1
+         and F <= 1024 and B + 1 <= FUSED_SCRATCH_WORDS, "textcnn_head shapes")
+    dconvs = []
+    cp, dp = (C.c_void_p * n)(), (C.c_void_p * n)()
+    P_, Co_ = (C.c_int32 * n)(), (C.c_int32 * n)()
+    for i, cv in enumerate(convs):
+        _chk_f32(cv, "conv")
+        _req(cv.is_contiguous() and cv.dim() == 2 and cv.shape[0] == B * Ps[i], "conv %d must be [B*P, Co]" % i)
+        dc = alloc(tuple(cv.shape), cv.device)
+        dconvs.append(dc)
+        cp[i], dp[i], P_[i], Co_[i] = cv.data_ptr(), dc.data_ptr(), Ps[i], cv.shape[1]
+    ws = _fused_scratch_ws(feat.device)
+    _call("cgn_textcnn_head_f32", feat.device, n, cp, dp, P_, Co_, B, _ptr(W), _ptr(bias), _ptr(c),
+          c.stride(0) if B > 1 else 1, float(w_ce), _ptr(feat), _ptr(arg), _ptr(stats), _ptr(ws), ws.numel() * 4)
+    return dconvs
+
+
+def conv_dx_from_dconv(Ks, dconvs, W, B, L, E):
+    """dcols_w = dconv_w @ W_w (layout 0 weights [Co, K*E]) for every width in ONE grouped MFMA launch; returns dcols."""
+    dev = dconvs[0].device
+    calls, dcols = [], []
+    for K, dc, w in zip(Ks, dconvs, W):
+        Co = dc.shape[1]
+        P = L - K + 1
+        _req(w.numel() == Co * K * E and w.is_contiguous() and dc.shape[0] == B * P, "conv weight / dconv shapes")
+        dl = alloc((B * P, K * E), dev)
+        calls.append((dc, w, dl, dict(M=B * P, N=K * E, K=Co, a_m=Axis(Co, 0, 0), a_k=Axis(1, 0, 0),
+                                      b_k=Axis(K * E, 0, 0), b_n=Axis(1, 0, 0), compute="f32")))
+        dcols.append(dl)
+    gemm_group(calls)
+    return dcols
+
+
+def col2im_rowdot(Ks, dcols, B, L, T, E, dx, other, rowdot, beta=0.0):
+    """dx [B*T, E] (contiguous): rows t < L = summed windows (+ beta*dx), rows t >= L zero (+ beta*dx);
+    rowdot[r] = dx[r] . other[r] (cgn_conv_col2im_rowdot_f32)."""
+    n = len(Ks)
+    _chk_f32(dx, "dx"), _chk_f32(other, "other"), _chk_f32(rowdot, "rowdot")
+    _req(dx.is_contiguous() and dx.shape == (B * T, E) and other.dim() == 2 and other.shape == (B * T, E)
+         and other.stride(1) == 1 and rowdot.is_contiguous() and rowdot.numel() == B * T, "col2im_rowdot shapes")
+    ptrs = (C.c_void_p * n)()
+    Karr = (C.c_int32 * n)(*Ks)
+    for i, (K, dl) in enumerate(zip(Ks, dcols)):
+        _chk_f32(dl, "dcols")
+        _req(dl.is_contiguous() and dl.shape == (B * (L - K + 1), K * E), "dcols %d shape" % i)
+        ptrs[i] = dl.data_ptr()
+    _call("cgn_conv_col2im_rowdot_f32", dx.device, n, ptrs, Karr, B, L, T, E, float(beta), _ptr(dx), _ptr(other),
+          other.stride(0), _ptr(rowdot))
+
+
 # Phase stamps (measurement aid, tools/step_stamps.py): while STAMPS is a dict {"buf": int64 device tensor, "names": []}
 # every stamp(name) call appends a 1-thread kernel that writes the device wall clock into the next slot when the CURRENT
 # stream gets there - also inside a captured graph, so an un-profiled replay can be timed phase by phase. None = no-op.

@@ -371,7 +371,8 @@ class CGNStep:
     # -------------------------------------------------------------------------------------------------------------
     # encoder forward (embedding -> highway -> biLSTM -> mu/logvar); `x_words` None => word part gathered from ids
     # -------------------------------------------------------------------------------------------------------------
-    def _encoder_fwd(self, enc_in, B, L):
+    def _encoder_fwd(self, enc_in, B, L, head=True):
+        """head=False: stop behind the biLSTM (the caller runs the fused code head, ops.code_head_fwd)."""
         cfg, P = self.cfg, self.P
         He, Z = cfg.encoder_rnn_size, cfg.latent_variable_size
         N = B * L
@@ -388,6 +389,8 @@ class CGNStep:
         ops.stamp("M encoder W_ih products done")
         engine.lstm_run_fwd([sf, sr], [P["encoder.rnn.weight_hh_l0"], P["encoder.rnn.weight_hh_l0_reverse"]])
         ops.stamp("M encoder LSTM fwd done")
+        if not head:
+            return dict(hw_out=hw_out, hw_saved=hw_saved, sf=sf, sr=sr, ctx=None, mulv=None, B=B, L=L)
         ctx = _new((B, 2 * He), self.dev)
         ops.copy2d(sf.c_final(), ctx[:, :He])
         ops.copy2d(sr.c_final(), ctx[:, He:])
@@ -402,19 +405,21 @@ class CGNStep:
             ops.gemm(ctx, P["e2logvar.weight"].t(), mulv[:, Z:], bias0=P["e2logvar.bias"], compute="f32")
         return dict(hw_out=hw_out, hw_saved=hw_saved, sf=sf, sr=sr, ctx=ctx, mulv=mulv, B=B, L=L)
 
-    def _encoder_bwd(self, es, dmulv, param_grads):
+    def _encoder_bwd(self, es, dmulv, param_grads, dc=None):
         """Backward of _encoder_fwd from d[mu|logvar]. param_grads True: write encoder parameter grads (G);
-        returns d(enc_in) [N, Din]."""
+        returns d(enc_in) [N, Din]. dc = (dcf, dcr): the final cell states' gradients are already there (fused code
+        head, ops.code_head_bwd); only the mu|logvar weight gradients are formed from dmulv then."""
         cfg, P, G = self.cfg, self.P, self.G
         He, Z = cfg.encoder_rnn_size, cfg.latent_variable_size
         B, L = es["B"], es["L"]
         N = B * L
         ctx = es["ctx"]
-        dctx = _new((B, 2 * He), self.dev)
+        dctx = _new((B, 2 * He), self.dev) if dc is None else None
         dmu, dlv = dmulv[:, :Z], dmulv[:, Z:]
         w2 = self._fused("e2.w", P)
         if w2 is not None:
-            ops.gemm(dmulv, w2, dctx, compute="f32")
+            if dc is None:
+                ops.gemm(dmulv, w2, dctx, compute="f32")
             if param_grads:
                 self.later(0, lambda: engine.linear_bwd(ctx, w2, dmulv, self._fused("e2.w", G), self._fused("e2.b", G)))
         else:
@@ -424,9 +429,12 @@ class CGNStep:
                 self.later(0, lambda: (engine.linear_bwd(ctx, P["e2mu.weight"], dmu, G["e2mu.weight"], G["e2mu.bias"]),
                                        engine.linear_bwd(ctx, P["e2logvar.weight"], dlv, G["e2logvar.weight"],
                                                          G["e2logvar.bias"])))
-        dcf, dcr = _new((B, He), self.dev), _new((B, He), self.dev)
-        ops.copy2d(dctx[:, :He], dcf)
-        ops.copy2d(dctx[:, He:], dcr)
+        if dc is None:
+            dcf, dcr = _new((B, He), self.dev), _new((B, He), self.dev)
+            ops.copy2d(dctx[:, :He], dcf)
+            ops.copy2d(dctx[:, He:], dcr)
+        else:
+            dcf, dcr = dc
         sf, sr = es["sf"], es["sr"]
         self.exclusive()
         dgf, dgr = engine.lstm_run_bwd([sf, sr], [P["encoder.rnn.weight_hh_l0"], P["encoder.rnn.weight_hh_l0_reverse"]],
@@ -562,19 +570,31 @@ class CGNStep:
         _cap_sel(capture, "enc/tdnn", tsaved["arg"])
         ops.stamp("M embedding + TDNN done")
         # ---- encode_for_z (cgn.py:83-103) + KLD (:1076) + [z,c] (:1080) ------------------------------------------
-        es = self._encoder_fwd(enc_in, B, L)
+        Wih0 = P["generator.rnn.weight_ih_l0"]
+        He = cfg.encoder_rnn_size
+        w2f = self._fused("e2.w", P)
+        # the code head (context -> mu|logvar -> z, KLD -> [z,c] -> its gate contribution) as ONE launch where the shapes
+        # allow (csrc/fused.hip); else the chain of copies, products and the reparametrisation kernel
+        fused_head = ops.code_head_eligible(B, He, Z, C, w2f, Wih0[:, E:])
+        es = self._encoder_fwd(enc_in, B, L, head=not fused_head)
         if capture is not None:
             for l, (_, pre) in enumerate(es["hw_saved"]):
                 _cap_sel(capture, "enc/hw%d" % l, pre[:, :Din] > 0)
-        mulv = es["mulv"]
         zc, std, kld = _new((B, Z + C), dev), _new((B, Z), dev), _new((1,), dev)
         if callable(c_target):
             c_target = c_target()  # data-parallel wake_sleep(): reduce + apply the discriminator gradients, then infer c
         ops.stamp("M mu|logvar done (waits for c now)")
         self.join(0)  # wake_sleep(): the discriminator step and c inference ran beside the encoder forward
         ops.stamp("M joined c")
-        cvec = c_target.reshape(B, C)
-        ops.reparam_kld_fwd(mulv, eps, cvec, zc, std, kld)
+        cvec = c_target.reshape(B, C).contiguous()
+        zg = _new((B, 4 * Hg), dev)
+        if fused_head:
+            es["ctx"], es["mulv"] = _new((B, 2 * He), dev), _new((B, 2 * Z), dev)
+            ops.code_head_fwd(es["sf"].c_final(), es["sr"].c_final(), w2f, self._fused("e2.b", P), eps, cvec,
+                              Wih0[:, E:], es["ctx"], es["mulv"], zc, std, kld, zg)
+        else:
+            ops.reparam_kld_fwd(es["mulv"], eps, cvec, zc, std, kld)
+        mulv = es["mulv"]
         # ---- generator (model/generator.py:45-64) --------------------------------------------------------------
         gen_emb = _new((NT, E), dev)
         ops.gather_rows(table, dec_word.reshape(-1), gen_emb,
@@ -584,11 +604,10 @@ class CGNStep:
                  and all(P["generator.rnn.%s_l%d" % (k, l)].is_contiguous() for k in ("weight_hh",) for l in (0, 1))
                  and P["generator.rnn.weight_ih_l1"].is_contiguous())
         g0, g1 = engine.LstmSeq(B, T, Hg, dev, False), engine.LstmSeq(B, T, Hg, dev, False, need_xg=not fuse2)
-        Wih0 = P["generator.rnn.weight_ih_l0"]
         ops.gemm(gen_emb, Wih0[:, :E].t(), g0.xg.view(NT, 4 * Hg), bias0=P["generator.rnn.bias_ih_l0"],
                  bias1=P["generator.rnn.bias_hh_l0"])
-        zg = _new((B, 4 * Hg), dev)
-        ops.gemm(zc, Wih0[:, E:].t(), zg)  # the tiled [z,c] input contributes once per sentence
+        if not fused_head:
+            ops.gemm(zc, Wih0[:, E:].t(), zg)  # the tiled [z,c] input contributes once per sentence
         g0.xg_extra = zg
         g0.set_initial()
         g1.set_initial()
@@ -624,16 +643,33 @@ class CGNStep:
         # (a loss that this step does not compute reads as the engine's constant zero: no fill kernel on the critical path)
         c_loss = self._zero1
         z_loss = _new((1,), dev) if calc_z_loss else self._zero1
+        F_disc = sum(self.Cos)
+        # the c-reconstruction head and col2im + row dot product as single launches (csrc/fused.hip) where they apply
+        fused_closs = ops.FUSED_CHAINS and use_disc and F_disc <= 1024 and B + 1 <= ops.FUSED_SCRATCH_WORDS
+        rowdot = _new((NT,), dev)
         if need_soft:
             # ---- soft embedding (cgn.py:1103-1108): softmax(logits/tau) @ E, probabilities formed in the A loader
             out_emb = _new((NT, E), dev)
             ops.gemm(logits, table, out_emb, a_exp=(inv_tau, lse), dyn=self._dyn())
             ops.stamp("M soft embedding done")
             d_out_emb = _new((NT, E), dev)
-            ops.fill(d_out_emb, 0.0)  # rows t = T-1 stay zero: out_embedding[:, :-1, :] (cgn.py:1108)
+            if not (fused_closs and train):
+                ops.fill(d_out_emb, 0.0)  # rows t = T-1 stay zero: out_embedding[:, :-1, :] (cgn.py:1108)
         if use_disc:
             # ---- c reconstruction through the frozen discriminator(s) (cgn.py:1114-1120) ---------------------------
-            for a in range(C):
+            for a in range(C if fused_closs else 0):
+                cw, cb = self._conv_params(P, a)
+                fcw, fcb = self._fc_params(P, a)
+                convs, Ps = engine.textcnn_conv_fwd(out_emb, B, L, E, T * E, cw, cb)  # rows t < L per sentence
+                feat_d, arg_d = _new((B, F_disc), dev), _new((B, F_disc), dev, torch.int32)
+                stats2 = _new((2,), dev)
+                dconvs = ops.textcnn_head(convs, Ps, B, fcw, fcb, cvec[:, a], cfg.lambda_c, feat_d, arg_d, stats2)
+                _cap_sel(capture, "soft%d/conv" % a, arg_d)
+                c_loss = stats2[0:1] if a == 0 else ops.lincomb([(1.0, c_loss), (1.0, stats2[0:1])])
+                if train:
+                    dcols = ops.conv_dx_from_dconv(self.Ks, dconvs, [w.view(w.shape[0], -1) for w in cw], B, L, E)
+                    ops.col2im_rowdot(self.Ks, dcols, B, L, T, E, d_out_emb, out_emb, rowdot, beta=0.0 if a == 0 else 1.0)
+            for a in range(0 if fused_closs else C):
                 cw, cb = self._conv_params(P, a)
                 feat_d, arg_d = engine.textcnn_features_fwd(out_emb, B, L, E, T * E, cw, cb)  # rows t < L per sentence
                 _cap_sel(capture, "soft%d/conv" % a, arg_d)
@@ -676,10 +712,10 @@ class CGNStep:
             return ce, kld, z_loss, c_loss, enc_loss, gen_loss
         # ---- backward through softmax/CE + soft embedding, fused, in place over the logits ----------------------
         ops.stamp("M c-loss chain done")
-        rowdot = _new((NT,), dev)
         dlogits_t = _new((V, NT), dev, torch.bfloat16) if store16 else None  # k-contiguous A operand of dW_fc
         if need_soft:
-            ops.rowdot(d_out_emb, out_emb, rowdot)
+            if not fused_closs or calc_z_loss:  # (the z-reconstruction pass added to d_out_emb after the fused dot product)
+                ops.rowdot(d_out_emb, out_emb, rowdot)
             ops.gemm(d_out_emb, table.t(), logits, c_t=dlogits_t,
                      softmax_bwd=dict(logits=logits, lse=lse, rowdot=rowdot, target=tgt, inv_tau=inv_tau,
                                       ce_scale=79.0 * inv_tau / NT), dyn=self._dyn())
@@ -729,13 +765,22 @@ class CGNStep:
         ops.stamp("M generator LSTM bwd done")
         dWih0 = G["generator.rnn.weight_ih_l0"]
         dsum = _new((B, 4 * Hg), dev)
-        ops.sum_time(dg0, dsum)
+        dzc = _new((B, Z + C), dev)
+        fused_head_bwd = fused_head and 4 * Hg <= 4096
+        if fused_head_bwd:
+            # sum over time, d[z,c], reparametrisation backward (+ KLD term) and d(context) in one launch (csrc/fused.hip)
+            dmulv = _new((B, 2 * Z), dev)
+            dc_enc = (_new((B, He), dev), _new((B, He), dev))
+            ops.code_head_bwd(dg0, Wih0[:, E:], mulv, eps, w2f, float(kld_coeff) / B, dsum, dzc, dmulv, dc_enc[0],
+                              dc_enc[1], dyn=self._dyn(2))
+        else:
+            ops.sum_time(dg0, dsum)
         self.later(1, lambda: (engine.lstm_param_grads(g0, dg0, (gen_emb, Axis(E, 0, 0)), dWih0[:, :E],
                                                        G["generator.rnn.weight_hh_l0"], G["generator.rnn.bias_ih_l0"],
                                                        G["generator.rnn.bias_hh_l0"]),
                                ops.gemm(dsum.t(), zc, dWih0[:, E:])))
-        dzc = _new((B, Z + C), dev)
-        ops.gemm(dsum, Wih0[:, E:], dzc)  # g = dzc[:, :Z] = d(79*CE + recon)/dz  (cgn.py:1099, 1142)
+        if not fused_head_bwd:
+            ops.gemm(dsum, Wih0[:, E:], dzc)  # g = dzc[:, :Z] = d(79*CE + recon)/dz  (cgn.py:1099, 1142)
         if capture is not None:
             self.join(1)
             capture["g"] = dzc[:, :Z].clone()
@@ -750,9 +795,12 @@ class CGNStep:
             self.later(1, lambda: (ops.stamp("S1 generator gradients done"), self._optim_step(opts[1]),
                                    ops.stamp("S1 generator Adam done")))
         # ---- encoder backward (cgn.py:1145-1149): kld_coef*KLD + z_out.backward(g) ---------------------------------
-        dmulv = _new((B, 2 * Z), dev)
-        ops.reparam_kld_bwd(mulv, eps, dzc, float(kld_coeff) / B, dmulv, dyn=self._dyn(2))
-        d_enc_in = self._encoder_bwd(es, dmulv, param_grads=True)
+        if fused_head_bwd:
+            d_enc_in = self._encoder_bwd(es, dmulv, param_grads=True, dc=dc_enc)
+        else:
+            dmulv = _new((B, 2 * Z), dev)
+            ops.reparam_kld_bwd(mulv, eps, dzc, float(kld_coeff) / B, dmulv, dyn=self._dyn(2))
+            d_enc_in = self._encoder_bwd(es, dmulv, param_grads=True)
         ops.stamp("M highway bwd (dX) done")
         dtf = _new((N, S), dev)
         ops.copy2d(d_enc_in[:, E:], dtf)

@@ -107,7 +107,9 @@ def test_error_codes_raise():
 
 
 STRUCTS = {"cgn_axis": _lib.Axis, "cgn_gemm_desc": _lib.GemmDesc, "cgn_lstm_fwd_seq": _lib.LstmFwdSeq,
-           "cgn_lstm_bwd_seq": _lib.LstmBwdSeq, "cgn_conv_widths": _lib.ConvWidths}
+           "cgn_lstm_bwd_seq": _lib.LstmBwdSeq, "cgn_conv_widths": _lib.ConvWidths,
+           "cgn_code_head_fwd": _lib.CodeHeadFwd, "cgn_code_head_bwd": _lib.CodeHeadBwd,
+           "cgn_lstm2_fwd": _lib.Lstm2Fwd, "cgn_lstm2_bwd": _lib.Lstm2Bwd}
 
 
 def test_struct_layouts_match_header(tmp_path):

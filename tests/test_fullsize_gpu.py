@@ -108,3 +108,29 @@ def test_full_size_uniform_logits_cross_entropy_is_log_vocab(dev):
     ce = eng.enc_gen_train(None, data["enc_word"], data["enc_char"], data["dec_word"], data["target"], c, data["eps"],
                            0.9, 0.8, calc_z_loss=False, train=False)[0]
     assert abs(float(ce) - math.log(ocfg.word_vocab_size)) < 1e-4
+
+
+def test_fused_chains_match_the_chains_of_small_kernels(dev, monkeypatch):
+    """csrc/fused.hip (code head forward / backward, c-reconstruction head, col2im + row dot product: one launch each)
+    against the chains of small kernels they replace (ops.FUSED_CHAINS = False), two full training steps at BASELINE
+    configs[1]: the arithmetic is the same up to summation order, so losses agree to 2e-6 and weights to 1e-6 of the
+    largest weight."""
+    from ldrs_amd.hip import ops
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "FUSED_CHAINS", fused)
+        model, eng, opts, ocfg = _build(dev)
+        data, _ = bench.device_data(O, ocfg, bench.BATCH, bench.SEQ, 99, dev)
+        losses = []
+        for i in range(2):
+            dl, c, eg = eng.wake_sleep(opts, data, 0.9, 0.8, calc_z_loss=(i == 1))
+            losses.append([float(x) for x in dl] + [float(x) for x in eg[:4]] + [float(c.sum())])
+        torch.cuda.synchronize()
+        res.append((model, losses))
+    (m1, l1), (m2, l2) = res
+    for a, b in zip(l1, l2):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 2e-6 * max(1.0, abs(x)), (a, b)
+    for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        err = (p - q).abs().max().item() / max(p.abs().max().item(), 1e-12)
+        assert err <= 1e-4, (n, err)  # (Adam's first updates are sign-like: see the persistent-vs-step test above)

@@ -67,6 +67,7 @@ host_ms = 1e3 * (time.perf_counter() - h0) / args.replays  # time the HOST needs
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / args.replays
+t = buf[:len(names)].cpu().tolist()  # the last of the back-to-back replays (the host was far ahead of the GPU)
 # host cost of each graph launch of one replay (one more, synchronised, replay with a clock around every launch)
 real_replay = torch.cuda.CUDAGraph.replay
 costs = []
@@ -84,7 +85,6 @@ g(0.88, 0.9, totals=False)
 one_host_us = 1e6 * (time.perf_counter() - h0)
 torch.cuda.CUDAGraph.replay = real_replay
 torch.cuda.synchronize()
-t = buf[:len(names)].cpu().tolist()
 t0 = min(t)
 lines = ["# un-profiled replay, %s %s: %d back-to-back replays, %.3f ms per step (stamp nodes included); stamps of the last"
          " replay, us since its first stamp; M = main stream, S0 / S1 = side streams" % (args.workload, args.compute,
