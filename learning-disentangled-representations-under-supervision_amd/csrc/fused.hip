@@ -63,6 +63,86 @@ struct CodeHeadFwd {
     int B, He, Z, C, G4;
 };
 
+// mu | logvar: a wave takes FOUR outputs at a time, lanes along k (16-byte loads of the weight rows); all loads of the
+// four rows are issued before the first is consumed (one output at a time was a chain of L2 round trips: 16 outputs x
+// ~1 us per wave). KI = quads per lane and row.
+template <int KI>
+__device__ __forceinline__ void mulv_phase(const CodeHeadFwd& p, const float* ctx_s, float* mulv_s, int b, int K2) {
+    constexpr int OB = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nout = 2 * p.Z;
+    for (int n0 = wave * OB; n0 < nout; n0 += (FZ_NT / 64) * OB) {
+        f32x4 w[OB][KI];
+#pragma unroll
+        for (int o = 0; o < OB; ++o) {
+            const float* wr = p.W2 + (long)min(n0 + o, nout - 1) * p.ldw2;
+#pragma unroll
+            for (int i = 0; i < KI; ++i) {
+                const int k = lane * 4 + i * 256;
+                w[o][i] = *reinterpret_cast<const f32x4*>(wr + (k < K2 ? k : 0));
+            }
+        }
+        float acc[OB];
+#pragma unroll
+        for (int o = 0; o < OB; ++o) acc[o] = 0.f;
+#pragma unroll
+        for (int i = 0; i < KI; ++i) {
+            const int k = lane * 4 + i * 256;
+            if (k < K2) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(ctx_s + k);
+#pragma unroll
+                for (int o = 0; o < OB; ++o)
+                    acc[o] += w[o][i][0] * x[0] + w[o][i][1] * x[1] + w[o][i][2] * x[2] + w[o][i][3] * x[3];
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < OB; ++o) {
+            const float v = wave_sum(acc[o]);
+            const int n = n0 + o;
+            if (lane == 0 && n < nout) {
+                const float r = v + p.b2[n];
+                mulv_s[n] = r;
+                p.mulv[(long)b * nout + n] = r;
+            }
+        }
+    }
+}
+
+// the tiled [z,c] input's share of the generator's layer-0 gates, once per sentence: 4 lanes per gate row (16-byte
+// loads), FOUR rows at a time per lane group; the pad columns of a row meet the zeros behind zc_s[Z+C). KQ = quads per lane
+template <int KQ>
+__device__ __forceinline__ void zg_phase(const CodeHeadFwd& p, const float* zc_s, int b, int ZC) {
+    constexpr int OB = 4;
+    const int tid = threadIdx.x, sub = tid & 3;
+    for (int n0 = (tid >> 2) * OB; n0 < p.G4; n0 += (FZ_NT / 4) * OB) {
+        f32x4 w[OB][KQ];
+#pragma unroll
+        for (int o = 0; o < OB; ++o) {
+            const float* wr = p.Wzc + (long)min(n0 + o, p.G4 - 1) * p.ldzc;
+#pragma unroll
+            for (int i = 0; i < KQ; ++i) {
+                const int k0 = sub * 4 + i * 16;
+                w[o][i] = *reinterpret_cast<const f32x4*>(wr + (k0 < ZC ? k0 : 0));
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < OB; ++o) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < KQ; ++i) {
+                const int k0 = sub * 4 + i * 16;
+                if (k0 < ZC) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(zc_s + k0);
+                    acc += w[o][i][0] * x[0] + w[o][i][1] * x[1] + w[o][i][2] * x[2] + w[o][i][3] * x[3];
+                }
+            }
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            if (sub == 0 && n0 + o < p.G4) p.zg[(long)b * p.G4 + n0 + o] = acc;
+        }
+    }
+}
+
 __global__ __launch_bounds__(FZ_NT) void code_head_fwd_kernel(const CodeHeadFwd p) {
     __shared__ __attribute__((aligned(16))) float ctx_s[CH_MAX_2HE];
     __shared__ float mulv_s[CH_MAX_2Z];
@@ -79,22 +159,9 @@ __global__ __launch_bounds__(FZ_NT) void code_head_fwd_kernel(const CodeHeadFwd 
     }
     for (int k = tid; k < CH_MAX_ZC; k += FZ_NT) zc_s[k] = 0.f;
     __syncthreads();
-    // mu | logvar: one wave per output, lanes along k (16-byte loads of the weight row)            (cgn.py:91-92)
-    for (int n = wave; n < 2 * Z; n += FZ_NT / 64) {
-        const float* wr = p.W2 + (long)n * p.ldw2;
-        float acc = 0.f;
-        for (int k = lane * 4; k < K2; k += 256) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(wr + k);
-            const f32x4 x = *reinterpret_cast<const f32x4*>(ctx_s + k);
-            acc += w[0] * x[0] + w[1] * x[1] + w[2] * x[2] + w[3] * x[3];
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            const float v = acc + p.b2[n];
-            mulv_s[n] = v;
-            p.mulv[(long)b * 2 * Z + n] = v;
-        }
-    }
+    // mu | logvar                                                                                  (cgn.py:91-92)
+    if (K2 <= 1024) mulv_phase<4>(p, ctx_s, mulv_s, b, K2);
+    else mulv_phase<8>(p, ctx_s, mulv_s, b, K2);
     __syncthreads();
     // z = eps * exp(0.5 logvar) + mu, [z, c], this sentence's KLD term                              (cgn.py:94-101, :1076-1080)
     float term = 0.f;
@@ -115,19 +182,8 @@ __global__ __launch_bounds__(FZ_NT) void code_head_fwd_kernel(const CodeHeadFwd 
     // the tiled [z,c] input's share of the generator's layer-0 gates, once per sentence: 4 lanes per gate row, 16-byte
     // loads; the pad columns of a row are multiplied by the zeros behind zc_s[Z+C)
     if (p.Wzc) {
-        const int sub = lane & 3;
-        for (int n = tid >> 2; n < p.G4; n += FZ_NT / 4) {
-            const float* wr = p.Wzc + (long)n * p.ldzc;
-            float acc = 0.f;
-            for (int k0 = sub * 4; k0 < ZC; k0 += 16) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(wr + k0);
-                const f32x4 x = *reinterpret_cast<const f32x4*>(zc_s + k0);
-                acc += w[0] * x[0] + w[1] * x[1] + w[2] * x[2] + w[3] * x[3];
-            }
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            if (sub == 0) p.zg[(long)b * p.G4 + n] = acc;
-        }
+        if (ZC <= 80) zg_phase<5>(p, zc_s, b, ZC);
+        else zg_phase<9>(p, zc_s, b, ZC);
     }
     if (publish_and_check_last(p.rows, p.ticket, b, -0.5f * term, (unsigned)p.B, &s_flag)) {
         if (wave == 0) {
@@ -161,44 +217,61 @@ struct CodeHeadBwd {
 };
 
 __global__ __launch_bounds__(FZ_NT) void code_head_bwd_kernel(const CodeHeadBwd p) {
-    __shared__ float dsum_s[CH_MAX_G4];
-    __shared__ float part_s[FZ_NT / 64][CH_MAX_ZC];
+    __shared__ __attribute__((aligned(16))) float dsum_s[CH_MAX_G4];
+    __shared__ __attribute__((aligned(16))) float part_s[FZ_NT / 64][CH_MAX_ZC];
     __shared__ float dzc_s[CH_MAX_ZC];
     __shared__ float dmulv_s[CH_MAX_2Z];
+    __shared__ __attribute__((aligned(16))) float half_s[CH_MAX_2HE];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int He = p.He, Z = p.Z, ZC = p.Z + p.C, G4 = p.G4, T = p.T;
-    // dsum = sum over time of the gate gradients (the [z,c] input is the same at every timestep)
-    for (int n = tid; n < G4; n += FZ_NT) {
+    // dsum = sum over time of the gate gradients (the [z,c] input is the same at every timestep): a thread owns four
+    // consecutive gate columns, 8 timesteps of 16-byte loads in flight (G4 % 4 == 0)
+    for (int n = tid * 4; n < G4; n += FZ_NT * 4) {
         const float* src = p.dg0 + (long)b * T * G4 + n;
-        float s = 0.f;
-        for (int t0 = 0; t0 < T; t0 += 8) {  // 8 loads in flight; fixed summation order
-            float v[8];
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int t0 = 0; t0 < T; t0 += 8) {  // fixed summation order
+            f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[(long)min(t0 + u, T - 1) * G4];
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (long)min(t0 + u, T - 1) * G4);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += (t0 + u < T) ? v[u] : 0.f;
+            for (int u = 0; u < 8; ++u)
+                if (t0 + u < T) s += v[u];
         }
-        dsum_s[n] = s;
-        p.dsum[(long)b * G4 + n] = s;
+        *reinterpret_cast<f32x4*>(dsum_s + n) = s;
+        *reinterpret_cast<f32x4*>(p.dsum + (long)b * G4 + n) = s;
     }
     __syncthreads();
-    // d[z,c][k] = sum_n dsum[n] W[n, k]: lanes along k (coalesced weight rows), each wave one slice of n
+    // d[z,c][k] = sum_n dsum[n] W[n, k]. A weight row is Z + C contiguous floats: LPR lanes take one quad each (a coalesced
+    // row segment), 64 / LPR rows per wave instruction, 16 instructions in flight; the lanes that hold the same quad of
+    // different rows are added at the end (shuffles), the 8 waves' row slices through LDS. Fixed summation order.
     {
+        const int nq = (ZC + 3) / 4;                       // quads per row (the last may reach into the row's zero padding)
+        const int lpr = nq <= 16 ? 16 : (nq <= 32 ? 32 : 64);
+        const int rpi = 64 / lpr;                          // rows per wave instruction
+        const int qi = lane % lpr, ri = lane / lpr;
+        const bool qok = qi < nq;
         const int ns = (G4 + FZ_NT / 64 - 1) / (FZ_NT / 64);
         const int n0 = wave * ns, n1 = min(G4, n0 + ns);
-        for (int kc = 0; kc < ZC; kc += 64) {
-            const int k = kc + lane;
-            const int kk = k < ZC ? k : 0;
-            float acc = 0.f;
-            for (int nb = n0; nb < n1; nb += 8) {
-                float w[8];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int nb = n0; nb < n1; nb += 16 * rpi) {
+            f32x4 w[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) w[u] = p.Wzc[(long)min(nb + u, n1 - 1) * p.ldzc + kk];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc += (nb + u < n1) ? w[u] * dsum_s[nb + u] : 0.f;
+            for (int u = 0; u < 16; ++u) {
+                const int n = min(nb + u * rpi + ri, n1 - 1);
+                w[u] = *reinterpret_cast<const f32x4*>(p.Wzc + (long)n * p.ldzc + (qok ? qi * 4 : 0));
             }
-            if (k < ZC) part_s[wave][k] = acc;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int n = nb + u * rpi + ri;
+                const float dn = (n < n1 && qok) ? dsum_s[n] : 0.f;
+                acc += w[u] * dn;
+            }
         }
+        for (int o = lpr; o < 64; o <<= 1) {  // add the rows that share a quad
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+        }
+        if (ri == 0 && qok) *reinterpret_cast<f32x4*>(&part_s[wave][qi * 4]) = acc;
     }
     __syncthreads();
     if (tid < ZC) {
@@ -222,18 +295,38 @@ __global__ __launch_bounds__(FZ_NT) void code_head_bwd_kernel(const CodeHeadBwd 
         p.dmulv[(long)b * 2 * Z + Z + tid] = dlv;
     }
     __syncthreads();
-    // d(context) = d[mu|logvar] . W2, split into the two final cell states' gradients: lanes along the context index
-    for (int j = tid; j < 2 * He; j += FZ_NT) {
-        float acc = 0.f;
-        for (int nb = 0; nb < 2 * Z; nb += 8) {
-            float w[8];
+    // d(context)[j] = sum_n d[mu|logvar][n] W2[n, j], split into the two final cell states' gradients. A thread owns four
+    // consecutive j (16-byte loads along the weight rows), the two halves of the workgroup take the two halves of n
+    // (16 rows in flight each) and meet in LDS; (2He) % 4 == 0, 2He <= 4 * 256.
+    {
+        const int K2 = 2 * He, N2 = 2 * Z;
+        const int half = tid >> 8, jt = (tid & 255) * 4;
+        const int nh = (N2 + 1) / 2;
+        const int nb0 = half * nh, nb1 = min(N2, nb0 + nh);
+        for (int j = jt; j < K2; j += 1024) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int nb = nb0; nb < nb1; nb += 16) {
+                f32x4 w[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) w[u] = p.W2[(long)min(nb + u, 2 * Z - 1) * p.ldw2 + j];
+                for (int u = 0; u < 16; ++u)
+                    w[u] = *reinterpret_cast<const f32x4*>(p.W2 + (long)min(nb + u, nb1 - 1) * p.ldw2 + j);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += (nb + u < 2 * Z) ? w[u] * dmulv_s[nb + u] : 0.f;
+                for (int u = 0; u < 16; ++u)
+                    if (nb + u < nb1) acc += w[u] * dmulv_s[nb + u];
+            }
+            if (half == 1) *reinterpret_cast<f32x4*>(half_s + j) = acc;
+            __syncthreads();  // (uniform: every thread runs the same number of j trips)
+            if (half == 0) {
+                acc += *reinterpret_cast<const f32x4*>(half_s + j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int jj = j + e;
+                    if (jj < He) p.dcf[(long)b * He + jj] = acc[e];
+                    else p.dcr[(long)b * He + jj - He] = acc[e];
+                }
+            }
+            __syncthreads();
         }
-        if (j < He) p.dcf[(long)b * He + j] = acc;
-        else p.dcr[(long)b * He + j - He] = acc;
     }
 }
 
@@ -411,7 +504,10 @@ extern "C" int cgn_code_head_bwd_f32(void* stream, const cgn_code_head_bwd* d) {
     CGN_CHECK_ARG(d->B > 0 && d->T > 0 && d->He > 0 && d->Z > 0 && d->C >= 0 && d->G4 > 0);
     CGN_CHECK_ARG(d->G4 <= CH_MAX_G4 && 2 * d->Z <= CH_MAX_2Z && d->Z + d->C <= CH_MAX_ZC && d->Z + d->C <= FZ_NT);
     CGN_CHECK_ARG(d->dg0 && d->Wzc && d->mulv && d->eps && d->W2 && d->dsum && d->dzc && d->dmulv && d->dcf && d->dcr);
-    CGN_CHECK_ARG(d->ldzc >= d->Z + d->C && d->ldw2 >= 2 * d->He);
+    CGN_CHECK_ARG(d->ldzc >= (d->Z + d->C + 3) / 4 * 4 && d->ldzc % 4 == 0 && d->ldw2 >= 2 * d->He && d->ldw2 % 4 == 0);
+    CGN_CHECK_ARG(d->G4 % 4 == 0 && d->He % 2 == 0 && 2 * d->He <= CH_MAX_2HE);
+    CGN_CHECK_ARG((uintptr_t)d->Wzc % 16 == 0 && (uintptr_t)d->W2 % 16 == 0 && (uintptr_t)d->dg0 % 16 == 0 &&
+                  (uintptr_t)d->dsum % 16 == 0);
     CodeHeadBwd p;
     p.dg0 = d->dg0; p.Wzc = d->Wzc; p.ldzc = d->ldzc; p.mulv = d->mulv; p.eps = d->eps; p.dyn_w = d->dyn_kld_w;
     p.W2 = d->W2; p.ldw2 = d->ldw2; p.dsum = d->dsum; p.dzc = d->dzc; p.dmulv = d->dmulv; p.dcf = d->dcf; p.dcr = d->dcr;
