@@ -169,10 +169,10 @@ def main():
     global_step = 5000
     kc, tau = kld_coef(global_step), temp_coef(global_step)
 
-    # The step is captured once into a hipGraph (hip/graph.py) and replayed; its schedules and Adam step counts live in
-    # device memory, so every replay is a full, different training step. N > 1 (data parallel): a chain of graph
-    # segments cut at the three gradient reductions, whose RCCL all-reduces are issued eagerly between the segments
-    # and overlap the next segment. CGN_DP_EAGER=1 (or a failed capture) keeps the kernel-by-kernel step.
+    # The step is captured once as one hipGraph per branch (hip/graph.py) and replayed; its schedules and Adam step counts
+    # live in device memory, so every replay is a full, different training step. N > 1 (data parallel): the same graphs,
+    # each stream's graph cut where that stream starts / waits for a gradient all-reduce; the RCCL calls are issued
+    # eagerly between the halves. CGN_DP_EAGER=1 (or a failed capture) keeps the kernel-by-kernel step.
     dp = world > 1 or args.force_dp
     want_graph = not args.eager and not (dp and os.environ.get("CGN_DP_EAGER") == "1")
 
@@ -481,7 +481,7 @@ def main():
     torch.cuda.synchronize()
     check_lstm()
     if rank == 0:
-        launch = (("hipGraph replay" if not dp else "hipGraph segments + eager RCCL all-reduce") if use_graph else
+        launch = (("hipGraph replay" if not dp else "per-branch hipGraphs + eager RCCL all-reduce on the producing streams") if use_graph else
                   ("eager" if eager_result is None or not want_graph else
                    "eager (faster here than the segmented-graph replay, which also ran)"))
         torch.cuda.synchronize()

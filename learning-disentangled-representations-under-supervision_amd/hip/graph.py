@@ -17,11 +17,13 @@ Nothing of the reference's semantics changes: the same kernels run in the same o
 step (tests/test_graph_gpu.py checks replayed training against eager training: losses 1e-6, weights 2e-6 — Adam's
 bias corrections are formed in double on the device instead of on the host).
 
-Data parallel runs (world_size > 1) replay the step as a CHAIN of graph segments cut at the communication points of
-CGNStep's data-parallel schedule (step.py `_comm`): segment, RCCL all-reduce calls issued eagerly on RCCL's own stream,
-next segment. The collectives themselves are never captured (nothing here depends on RCCL being capturable); what the
-segmentation keeps is the one-launch-per-segment host cost and the overlap: the generator's gradient all-reduce
-travels while the encoder-backward segment runs, the encoder's while the generator's Adam segment runs.
+Data parallel runs (world_size > 1) replay the SAME per-branch graphs; every communication point of the step (CGNStep._comm:
+begin / wait of one optimizer group's gradient all-reduce) cuts the graph of the stream it occurs on - the side stream that
+formed the group's last gradient, or the main stream - and the RCCL calls are issued eagerly between the two halves with
+that stream current. The collectives themselves are never captured (nothing here depends on RCCL being capturable) and no
+other stream is joined for them: the generator's all-reduce travels beside the encoder's dX chain, the discriminator's
+beside the encoder forward (round 2 cut ONE chain of segments at every collective and gave up the deferral: +13 % on one
+rank).
 """
 import warnings
 
@@ -31,39 +33,6 @@ from . import ops
 
 INPUT_KEYS = ("x_labelled", "y_labelled", "x_generated", "c_generated", "mask_labelled", "mask_generated", "enc_word",
               "enc_char", "dec_word", "target", "c_uniform", "eps")
-
-
-class _SegmentRecorder:
-    """Captures one pass of the step into consecutive hipGraphs that share a memory pool; CGNStep._comm calls cut()."""
-
-    def __init__(self, thread_local):
-        self.segments = []  # [(graph, [actions run after it])]
-        self.pool = torch.cuda.graph_pool_handle()
-        self.g = None
-        # with a process group alive, its watchdog thread may touch HIP events while this thread captures
-        self.kw = dict(capture_error_mode="thread_local") if thread_local else {}
-
-    def begin(self):
-        self.g = torch.cuda.CUDAGraph()
-        self.g.capture_begin(pool=self.pool, **self.kw)
-
-    def cut(self, actions):
-        self.g.capture_end()
-        self.segments.append((self.g, actions))
-        self.begin()
-
-    def end(self):
-        self.g.capture_end()
-        self.segments.append((self.g, []))
-        self.g = None
-
-    def abort(self):
-        if self.g is not None:
-            try:
-                self.g.capture_end()
-            except Exception:
-                pass
-            self.g = None
 
 
 class _BranchRecorder:
@@ -85,10 +54,15 @@ class _BranchRecorder:
         self.main_stream = main_stream
         self.pool = torch.cuda.graph_pool_handle()
         self.kw = dict(capture_error_mode="thread_local") if thread_local else {}
-        self.segments = []   # ("main", graph, [side streams to wait for first]) | ("side", graph, k)
+        # ("main", graph, [side streams to wait for first]) | ("side", graph, k, forks) | ("comm", actions, k | None):
+        # forks = True for the graph that opens a side region (it starts behind the fork event), False for the graph that
+        # continues the region behind a communication point (same stream: stream order)
+        self.segments = []
         self.g = None        # main graph being captured
         self.waits = []      # joins that the NEXT main graph starts with
         self.side_g = None
+        self.side_k = None
+        self.side_first = True
 
     def _begin_main(self):
         self.g = torch.cuda.CUDAGraph()
@@ -107,19 +81,39 @@ class _BranchRecorder:
     def begin(self):
         self._begin_main()
 
+    def _begin_side_graph(self):
+        self.side_g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(self._side_stream):
+            self.side_g.capture_begin(pool=self.pool, **self.kw)
+
+    def _end_side_graph(self):
+        with torch.cuda.stream(self._side_stream), warnings.catch_warnings():
+            warnings.filterwarnings("ignore", message="The CUDA Graph is empty")
+            self.side_g.capture_end()
+        self.segments.append(("side", self.side_g, self.side_k, self.side_first))
+        self.side_g, self.side_first = None, False
+
     def begin_side(self, k, stream):
         self._end_main()
-        self.side_g = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(stream):
-            self.side_g.capture_begin(pool=self.pool, **self.kw)
-        self._side_stream = stream
+        self._side_stream, self.side_k, self.side_first = stream, k, True
+        self._begin_side_graph()
 
     def end_side(self, k):
-        with torch.cuda.stream(self._side_stream):
-            self.side_g.capture_end()
-        self.segments.append(("side", self.side_g, k))
-        self.side_g = None
+        self._end_side_graph()
+        self.side_k = None
         self._begin_main()
+
+    def comm(self, actions):
+        """A communication point on the stream being captured right now: its graph ends, the actions follow it, a new
+        graph continues the stream."""
+        if self.side_g is not None:
+            self._end_side_graph()
+            self.segments.append(("comm", actions, self.side_k))
+            self._begin_side_graph()
+        else:
+            self._end_main()
+            self.segments.append(("comm", actions, None))
+            self._begin_main()
 
     def join(self, k):
         self._end_main()
@@ -181,23 +175,7 @@ class GraphedWakeSleep:
             ops.KEEP = []
             try:
                 with ops.capture_without_gc():  # a collector run inside a capture can abort the process (ops.py)
-                    if eng.dp:
-                        torch.cuda.empty_cache()
-                        rec = _SegmentRecorder(thread_local=torch.distributed.is_initialized())
-                        eng.recorder = rec
-                        try:
-                            with torch.cuda.stream(self.stream):
-                                rec.begin()
-                                try:
-                                    self.out = self._run()
-                                    rec.end()
-                                except BaseException:
-                                    rec.abort()
-                                    raise
-                        finally:
-                            eng.recorder = None
-                        self.segments = rec.segments
-                    elif overlap and branch_graphs:
+                    if eng.dp or (overlap and branch_graphs):
                         torch.cuda.empty_cache()
                         rec = _BranchRecorder(self.stream, thread_local=torch.distributed.is_initialized())
                         eng.recorder = rec
@@ -235,29 +213,47 @@ class GraphedWakeSleep:
         done, held = {}, []
 
         def launch_sides():
-            for g, k, fork in held:
+            for item in held:
+                k = item[2]
                 st = sides[k]
-                st.wait_event(fork)
                 with torch.cuda.stream(st):
-                    g.replay()
+                    if item[0] == "side":
+                        if item[3] is not None:
+                            st.wait_event(item[3])
+                        item[1].replay()
+                    else:  # communication point on this side stream (RCCL orders itself behind the stream's work so far)
+                        for kind, group in item[1]:
+                            self.progress = (self.calls, "S%d" % k, kind + " " + group)
+                            eng.do_comm(kind, group)
                     ev = torch.cuda.Event()
                     ev.record(st)
                 done[k] = ev
             del held[:]
 
-        for kind, g, arg in self.branches:
+        for seg in self.branches:
+            kind = seg[0]
             if kind == "main":
-                if arg:
+                g, waits = seg[1], seg[2]
+                if waits:
                     launch_sides()
-                    for k in arg:
+                    for k in waits:
                         if k in done:
                             main.wait_event(done.pop(k))
                 g.replay()
                 launch_sides()
-            else:
-                fork = torch.cuda.Event()
-                fork.record(main)
-                held.append((g, arg, fork))
+            elif kind == "side":
+                fork = None
+                if seg[3]:  # opens a side region: behind everything the main stream has been given so far
+                    fork = torch.cuda.Event()
+                    fork.record(main)
+                held.append(("side", seg[1], seg[2], fork))
+            elif seg[2] is not None:  # communication point on a side stream: keeps its place in that stream's sequence
+                held.append(("comm", seg[1], seg[2]))
+            else:  # communication point on the main stream
+                launch_sides()
+                for kind_, group in seg[1]:
+                    self.progress = (self.calls, "M", kind_ + " " + group)
+                    eng.do_comm(kind_, group)
         launch_sides()
         for ev in done.values():  # nothing of this step may still run when the caller's stream moves on
             main.wait_event(ev)
@@ -286,16 +282,26 @@ class GraphedWakeSleep:
         eng = self.eng
         if data is not None:
             self.load(data)
-        eng.set_step_scalars(kld_coeff, temperature, self.NT, self.B, self._slot())
-        if self.branches is not None:
-            self._replay_branches()
-        for i, (g, actions) in enumerate(self.segments or ()):
-            self.progress = (self.calls, i, "replay")
-            g.replay()
-            for kind, group in actions:
-                self.progress = (self.calls, i, kind + " " + group)
-                eng.do_comm(kind, group)
-        self.progress = (self.calls, len(self.segments or ()), "done")
+        # The replay runs on this object's OWN stream (the caller's stream waits for it at the end). Why: HIP multiplexes
+        # streams onto 4 hardware queues in creation order; the caller's stream is normally the null stream (queue 0), and
+        # the 4th stream created after it - RCCL's internal stream in a data-parallel run - lands on queue 0 as well. A
+        # collective that waits for a side stream's gradients then blocks the queue's head, and with it the whole main
+        # chain (measured: the dX chain started 620 us late, --force-dp 3.38 ms against 2.98 ms; on its own stream
+        # [queue 1, idle otherwise] the main chain shares a queue with nothing).
+        cur = torch.cuda.current_stream(eng.dev)
+        own = cur.cuda_stream != self.stream.cuda_stream
+        if own:
+            self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            eng.set_step_scalars(kld_coeff, temperature, self.NT, self.B, self._slot())
+            if self.branches is not None:
+                self._replay_branches()
+            for i, (g, actions) in enumerate(self.segments or ()):  # (one graph: overlap off, or branch_graphs=False)
+                self.progress = (self.calls, i, "replay")
+                g.replay()
+        if own:
+            cur.wait_stream(self.stream)
+        self.progress = (self.calls, "-", "done")
         self._bump_host_steps()
         d_losses, c, eg = self.out
         ce, kld, z_loss, c_loss = eg[:4]

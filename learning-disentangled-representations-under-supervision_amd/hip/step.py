@@ -160,10 +160,12 @@ class CGNStep:
     #   * later(k, fn): parameter-gradient work that nothing on the critical path needs is not forked where its inputs
     #     become ready (that would put it beside the next LSTM launch) but queued, and flush() forks all of it behind
     #     the LAST LSTM launch of the step, spread over the side streams, where it overlaps the dX chain's GEMMs.
-    # Eager mode (overlap off), data-parallel runs (gradients are wanted early for the all-reduce) and capture (tests
-    # read gradients at fixed points) run later() at once.
+    # Eager mode (overlap off) and capture (tests read gradients at fixed points) run later() at once.
+    # Data-parallel runs keep this schedule (round 3): each optimizer group's all-reduce is started on the stream that
+    # produced the group's last gradient and waited for on that same stream, right in front of the group's Adam kernel
+    # (_optim_step), so the generator's gradients travel beside the dX chain and no stream is joined for a collective.
     def exclusive(self):
-        if self.overlap and not self.dp:
+        if self.overlap:
             self.join(0, 1)
 
     def later(self, k, fn):
@@ -174,7 +176,7 @@ class CGNStep:
                 fn()
 
     def begin_defer(self, capture):
-        self._deferring = bool(self.overlap and not self.dp and capture is None)
+        self._deferring = bool(self.overlap and capture is None)
 
     def flush(self, only=None):
         """Fork the queued work now. only=k: just side stream k's share (the rest stays queued, and later() keeps
@@ -251,14 +253,14 @@ class CGNStep:
             self.allreduce.wait(self._pending.pop(group))
 
     def _comm(self, actions):
-        """A communication point of the data-parallel schedule. Eager: run the actions. While a step is being recorded
-        (hip/graph.py) the side streams are joined, the current graph segment ends here and the actions are attached
-        to it: a replay launches the segment, then runs them, then launches the next segment."""
+        """A communication point of the data-parallel schedule, on the CURRENT stream (main or a side stream). Eager:
+        run the actions. While a step is being recorded (hip/graph.py) the graph being captured on this stream ends
+        here and the actions are attached behind it: a replay launches that graph, runs the actions with this stream
+        current, then launches the graph that continues the stream. No other stream is joined."""
         if not self.dp:
             return
         if self.recorder is not None:
-            self.join(0, 1)
-            self.recorder.cut(list(actions))
+            self.recorder.comm(list(actions))
             return
         for kind, group in actions:
             self.do_comm(kind, group)
@@ -469,8 +471,7 @@ class CGNStep:
                 if ops.STAMPS is not None:
                     self.later(0, lambda: ops.stamp("S0 encoder LSTM dW done"))
                 self.flush()
-        if (param_grads and self.overlap and not self.dp and getattr(self.recorder, "parallel", False)
-                and not HW_DW_EARLY):
+        if param_grads and self.overlap and getattr(self.recorder, "parallel", False) and not HW_DW_EARLY:
             self._deferring = True  # the highway's dW products wait for the end of the dX chain (one more branch graph)
         turn = [0]
 
@@ -498,28 +499,6 @@ class CGNStep:
             return self._wake_sleep(opts, d, kld_coeff, temperature, calc_z_loss)
 
     def _wake_sleep(self, opts, d, kld_coeff, temperature, calc_z_loss):
-        if self.dp:
-            # Data-parallel schedule, four segments with three reductions between them:
-            #   [disc gradients || embedding + encoder forward] -> reduce disc (1.5 MB) -> [disc Adam, c inference,
-            #   generator forward, losses, generator backward] -> START reduce gen (57 MB) -> [encoder backward, which
-            #   does not need it] -> wait gen, START reduce enc (38 MB) -> [gen Adam] -> wait enc -> [enc Adam]
-            with self.side(0):
-                d_losses = self.disc_train(opts["disc"], d["x_labelled"], d["y_labelled"], d["x_generated"],
-                                           d["c_generated"], d.get("mask_labelled"), d.get("mask_generated"), step=False)
-            c_box = []
-
-            def late_c():
-                self.join(0)
-                self._comm([("begin", "disc"), ("wait", "disc")])
-                self._adam(opts["disc"])
-                c_box.append(self.infer_c(d["enc_word"], d["c_uniform"])[0])
-                return c_box[0]
-
-            eg_losses = self.enc_gen_train((opts["enc"], opts["gen"]), d["enc_word"], d["enc_char"], d["dec_word"],
-                                           d["target"], late_c, d["eps"], kld_coeff, temperature,
-                                           calc_z_loss=calc_z_loss)
-            self.join(0, 1)
-            return d_losses, c_box[0], eg_losses
         ops.stamp("M step begin")
         with self.side(0):
             ops.stamp("S0 disc step begin")
@@ -581,8 +560,6 @@ class CGNStep:
             for l, (_, pre) in enumerate(es["hw_saved"]):
                 _cap_sel(capture, "enc/hw%d" % l, pre[:, :Din] > 0)
         zc, std, kld = _new((B, Z + C), dev), _new((B, Z), dev), _new((1,), dev)
-        if callable(c_target):
-            c_target = c_target()  # data-parallel wake_sleep(): reduce + apply the discriminator gradients, then infer c
         ops.stamp("M mu|logvar done (waits for c now)")
         self.join(0)  # wake_sleep(): the discriminator step and c inference ran beside the encoder forward
         ops.stamp("M joined c")
@@ -785,13 +762,11 @@ class CGNStep:
             self.join(1)
             capture["g"] = dzc[:, :Z].clone()
             capture["gen_grads"] = {n: g.clone() for n, g in self.arenas["gen"].grads.items()}
-        if self.dp:
-            if not joint:
-                self.join(1)
-                self._comm([("begin", "gen")])  # travels while the encoder's backward pass runs
-        elif not joint:
+        if not joint:
             # the generator's Adam step follows its gradients (cgn.py:1143); the encoder backward does not wait for it.
-            # dzc above was the last read of a generator weight on the main stream.
+            # dzc above was the last read of a generator weight on the main stream. (Data parallel: _optim_step starts
+            # the all-reduce of the generator's gradient arena here, on the stream that formed the gradients, and waits
+            # for it on that stream: it travels beside the encoder's backward pass.)
             self.later(1, lambda: (ops.stamp("S1 generator gradients done"), self._optim_step(opts[1]),
                                    ops.stamp("S1 generator Adam done")))
         # ---- encoder backward (cgn.py:1145-1149): kld_coef*KLD + z_out.backward(g) ---------------------------------
@@ -812,19 +787,13 @@ class CGNStep:
         ops.stamp("M joined side streams")
         if capture is not None:
             capture["enc_grads"] = {n: g.clone() for n, g in self.arenas["enc"].grads.items()}
-        if self.dp:
-            if joint:  # initial VAE training: one optimizer over everything (cgn.py:623,645)
-                self._comm([("begin", "enc"), ("begin", "gen"), ("wait", "enc")])
-                self._adam(opts[0])
-                self._comm([("wait", "gen")])
-                self._adam(opts[1])
-            else:
-                self._comm([("wait", "gen"), ("begin", "enc")])
-                self._adam(opts[1])  # cgn.py:1143 (its update touches nothing the encoder backward read)
-                self._comm([("wait", "enc")])
-                self._adam(opts[0])  # cgn.py:1149
+        if self.dp and joint:  # initial VAE training: one optimizer over everything (cgn.py:623,645)
+            self._comm([("begin", "enc"), ("begin", "gen"), ("wait", "enc")])
+            self._adam(opts[0])
+            self._comm([("wait", "gen")])
+            self._adam(opts[1])
         else:
             self._optim_step(opts[0])  # cgn.py:1149
             if joint:
-                self._optim_step(opts[1])  # initial VAE training: one optimizer over everything (cgn.py:623,645)
+                self._optim_step(opts[1])
         return ce, kld, z_loss, c_loss, enc_loss, gen_loss

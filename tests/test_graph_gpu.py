@@ -97,10 +97,10 @@ def one_rank_group(dev):
 
 @pytest.mark.parametrize("graphed,calc_z", [(False, False), (True, False), (True, True)])
 def test_data_parallel_schedule_one_rank_matches_plain_step(dev, one_rank_group, graphed, calc_z):
-    """The data-parallel schedule (disc gradients reduced before disc Adam and c inference, generator gradients
-    reduced beside the encoder backward, encoder gradients beside the generator's Adam) with real RCCL calls on a
-    one-rank group — eager, and as a chain of graph segments with the collectives between them — must train exactly
-    like the plain step (a one-rank sum is the identity)."""
+    """The data-parallel schedule (each optimizer group's gradients all-reduced on the stream that formed them, right in
+    front of the group's Adam kernel: disc before c inference, generator beside the encoder's dX chain, encoder at the
+    end) with real RCCL calls on a one-rank group — eager, and as per-branch graphs with the collectives between them —
+    must train exactly like the plain step (a one-rank sum is the identity)."""
     from ldrs_amd import parallel
     from ldrs_amd.hip.graph import GraphedWakeSleep
     m_e, eng_e, opts_e, ocfg = _build(dev)
@@ -117,7 +117,10 @@ def test_data_parallel_schedule_one_rank_matches_plain_step(dev, one_rank_group,
     got = []
     if graphed:
         g = GraphedWakeSleep(eng_d, opts_d, data[0], calc_z_loss=calc_z, warmup_kld=SCHED[0][0], warmup_tau=SCHED[0][1])
-        assert len(g.segments) == 5 and sum(len(a) for _, a in g.segments) == 6
+        # one communication point per optimizer group, each on the stream that formed the group's last gradient:
+        # discriminator on side stream 0, generator on side stream 1, encoder on the main stream
+        comms = [(seg[2], [grp for _, grp in seg[1]]) for seg in g.branches if seg[0] == "comm"]
+        assert comms == [(0, ["disc", "disc"]), (1, ["gen", "gen"]), (None, ["enc", "enc"])], comms
         for (kc, tau), d in zip(SCHED[1:], data[1:]):
             dl, c, eg = g(kc, tau, d)
             got.append([float(x) for x in dl] + [float(x) for x in eg[:4]] + [float(c.sum())])

@@ -23,6 +23,7 @@ ap.add_argument("--workload", default="cfg2")
 ap.add_argument("--compute", default="f32")
 ap.add_argument("--replays", type=int, default=30)
 ap.add_argument("--out")
+ap.add_argument("--force-dp", action="store_true", help="the data-parallel schedule on a one-rank RCCL group")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 cfgd, B, L = bench.WORKLOADS[args.workload]
@@ -30,6 +31,12 @@ cfg = bench.make_config(Config, cfgd)
 ops.set_compute(args.compute)
 torch.manual_seed(1234)
 model = Controlled_Generation_Sentence(cfg, synthetic.synthetic_word_embed(cfg)).cuda()
+if args.force_dp:
+    from ldrs_amd import parallel
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29512")
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1)
+    parallel.attach(model, force=True)
 eng = model.step_engine()
 opts = dict(disc=eng.new_optimizer("disc"), enc=eng.new_optimizer("enc"), gen=eng.new_optimizer("gen"))
 data, _ = bench.device_data(synthetic, cfg, B, L, 1234, dev)
@@ -100,6 +107,8 @@ for i in order:
     last[st] = us
 text = "\n".join(lines)
 print(text)
+if args.force_dp:
+    torch.distributed.destroy_process_group()
 if args.out:
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     open(args.out, "w").write(text + "\n")
