@@ -43,6 +43,15 @@ int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out
             bt = 128;
         else
             bt = 64;
+        // Padding: the 128-wide tile grid may cover much more than M x N (the soft embedding's N = 300 pads to 384, its
+        // M = 1344 to 1408: 0.75 of the MFMA work is real). The 64-tile's lower steady-state rate (0.86 against 0.92 of
+        // peak, profiles/r02_gemm_table.txt) is the smaller loss then: 1344 x 320 covers 0.94. Measured on that product
+        // (tools/gemm_bench.py, profiles/r03_softemb_tile.txt): 171 -> 146 us alone, -28 us per step.
+        if (bt == 128 && !(d->epilogue == CGN_EPI_SOFTMAX_BWD) && !(d->storage != 0)) {
+            const double a128 = (double)cgn_cdiv(d->M, 128) * 128.0 * (double)cgn_cdiv(d->N, 128) * 128.0;
+            const double a64 = (double)cgn_cdiv(d->M, 64) * 64.0 * (double)cgn_cdiv(d->N, 64) * 64.0;
+            if (0.86 / a64 > 1.05 * 0.92 / a128) bt = 64;
+        }
     }
     const long tiles = bt == 128 ? t128 : t64;
     if (splitk <= 0 && bt == 128 && d->K >= 4096) {  // tall-K only: a split of the K = 1344 dW_fc product (sk 2) won 11 %

@@ -26,6 +26,8 @@ LIN = Axis(1, 0, 0)
 TAIL_HINT = {k: int(os.environ[e]) for k, e in (("splitk", "CGN_TAIL_SPLITK"), ("tile", "CGN_TAIL_TILE"))
              if os.environ.get(e)}
 HW_DW_EARLY = os.environ.get("CGN_HW_DW_EARLY") == "1"
+SOFTEMB_TILE = int(os.environ.get("CGN_SOFTEMB_TILE", "0"))
+SOFTEMB_SPLITK = int(os.environ.get("CGN_SOFTEMB_SPLITK", "0"))
 
 
 def _new(shape, dev, dtype=torch.float32):
@@ -84,6 +86,17 @@ class CGNStep:
         self.world_size = world_size
         self.dp = allreduce is not None and (world_size > 1 or force_dp)
         self._pending = {}     # optimizer group -> handles of its gradient all-reduce in flight
+        # The encoder group's gradients become final in two waves: the biLSTM's and the mu|logvar head's right behind the
+        # LSTM backward (side stream 0), the highway's, the TDNN's and the char table's only at the very end of the step.
+        # Its arena is laid out in that order (registration order: embedding, highway, rnn, e2*), so the all-reduce is
+        # split at the first LSTM weight: "enc.a" (the late-registered, EARLY-final 22 MB at cfg2) travels beside the dX
+        # chain, only "enc.b" (16 MB) is left for the end of the step.
+        a = self.arenas["enc"]
+        cut = a.offsets["encoder.rnn.weight_ih_l0"][0] if "encoder.rnn.weight_ih_l0" in a.offsets else a.size
+        early = [n for n, (o, _, _, _) in a.offsets.items() if o >= cut]
+        ok = all(n.startswith("encoder.rnn.") or n.startswith("e2") for n in early) and 0 < cut < a.size
+        self._enc_cut = cut if ok else None
+        self._split_enc = False
         self.recorder = None   # hip/graph.py: while set, every communication point ends one graph segment
         cfg = self.cfg
         # Stream overlap (off by default: in eager mode the host, not the GPU, is the bound and every fork/join costs two
@@ -241,14 +254,24 @@ class CGNStep:
     def _optim_step(self, state):
         if self.dp:
             g = state.arena.group
-            self._comm([("begin", g), ("wait", g)])
+            if g == "enc" and self._split_enc:  # "enc.a" was started behind the LSTM backward (_encoder_bwd)
+                self._comm([("begin", "enc.b"), ("wait", "enc.a"), ("wait", "enc.b")])
+                self._split_enc = False
+            else:
+                self._comm([("begin", g), ("wait", g)])
         self._adam(state)
 
     def do_comm(self, kind, group):
         """Run one communication action now: ("begin", g) starts the all-reduce of group g's gradient arena on RCCL's
         stream (ordered after the current stream), ("wait", g) orders the current stream after it."""
         if kind == "begin":
-            self._pending[group] = self.allreduce.begin(self.arenas[group].g)
+            if group == "enc.a":
+                flat = self.arenas["enc"].g[self._enc_cut:]
+            elif group == "enc.b":
+                flat = self.arenas["enc"].g[:self._enc_cut]
+            else:
+                flat = self.arenas[group].g
+            self._pending[group] = self.allreduce.begin(flat)
         else:
             self.allreduce.wait(self._pending.pop(group))
 
@@ -470,6 +493,8 @@ class CGNStep:
             if param_grads and i == 0:
                 if ops.STAMPS is not None:
                     self.later(0, lambda: ops.stamp("S0 encoder LSTM dW done"))
+                if self._split_enc:  # data parallel: the early-final part of the encoder's gradients starts to travel
+                    self.later(0, lambda: self._comm([("begin", "enc.a")]))
                 self.flush()
         if param_grads and self.overlap and getattr(self.recorder, "parallel", False) and not HW_DW_EARLY:
             self._deferring = True  # the highway's dW products wait for the end of the dX chain (one more branch graph)
@@ -627,7 +652,8 @@ class CGNStep:
         if need_soft:
             # ---- soft embedding (cgn.py:1103-1108): softmax(logits/tau) @ E, probabilities formed in the A loader
             out_emb = _new((NT, E), dev)
-            ops.gemm(logits, table, out_emb, a_exp=(inv_tau, lse), dyn=self._dyn())
+            ops.gemm(logits, table, out_emb, a_exp=(inv_tau, lse), dyn=self._dyn(), force_tile=SOFTEMB_TILE,
+                     force_splitk=SOFTEMB_SPLITK)
             ops.stamp("M soft embedding done")
             d_out_emb = _new((NT, E), dev)
             if not (fused_closs and train):
@@ -770,6 +796,7 @@ class CGNStep:
             self.later(1, lambda: (ops.stamp("S1 generator gradients done"), self._optim_step(opts[1]),
                                    ops.stamp("S1 generator Adam done")))
         # ---- encoder backward (cgn.py:1145-1149): kld_coef*KLD + z_out.backward(g) ---------------------------------
+        self._split_enc = bool(self.dp and not joint and self._enc_cut is not None)
         if fused_head_bwd:
             d_enc_in = self._encoder_bwd(es, dmulv, param_grads=True, dc=dc_enc)
         else:

@@ -117,10 +117,12 @@ def test_data_parallel_schedule_one_rank_matches_plain_step(dev, one_rank_group,
     got = []
     if graphed:
         g = GraphedWakeSleep(eng_d, opts_d, data[0], calc_z_loss=calc_z, warmup_kld=SCHED[0][0], warmup_tau=SCHED[0][1])
-        # one communication point per optimizer group, each on the stream that formed the group's last gradient:
-        # discriminator on side stream 0, generator on side stream 1, encoder on the main stream
+        # the communication points, each on the stream that formed the gradients: discriminator on side stream 0,
+        # generator on side stream 1, the encoder's early-final part (biLSTM, mu|logvar) on side stream 0 behind the LSTM
+        # backward, the rest of the encoder group on the main stream at the end
         comms = [(seg[2], [grp for _, grp in seg[1]]) for seg in g.branches if seg[0] == "comm"]
-        assert comms == [(0, ["disc", "disc"]), (1, ["gen", "gen"]), (None, ["enc", "enc"])], comms
+        assert comms == [(0, ["disc", "disc"]), (1, ["gen", "gen"]), (0, ["enc.a"]),
+                         (None, ["enc.b", "enc.a", "enc.b"])], comms
         for (kc, tau), d in zip(SCHED[1:], data[1:]):
             dl, c, eg = g(kc, tau, d)
             got.append([float(x) for x in dl] + [float(x) for x in eg[:4]] + [float(c.sum())])

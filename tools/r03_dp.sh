@@ -17,3 +17,8 @@ DP2_DIAG=20 DP2_WATCHDOG=90 timeout -k 10 240 python -m torch.distributed.run --
 rc=$?
 grep "^dp2 " $out/dp2.log | tee -a $out/summary.txt
 [ $rc -eq 0 ] || { tail -30 $out/dp2.log; exit $rc; }
+timeout -k 10 200 python tools/step_stamps.py --force-dp --out $out/stamps_force_dp.txt 2>&1 | grep -v "amdgpu.ids\|RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|socket.cpp" | head -3
+DP2_DIAG=20 DP2_WATCHDOG=90 timeout -k 10 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 tools/dp2_gpu_check.py --graphed > $out/dp2_graphed.log 2>&1
+rc=$?
+grep "^dp2 " $out/dp2_graphed.log | tee -a $out/summary.txt
+[ $rc -eq 0 ] || { tail -30 $out/dp2_graphed.log; exit $rc; }
