@@ -83,6 +83,9 @@ int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out
         const bool few = tiles < 64;
         const int min_k = few ? 128 : (bt == 128 ? 512 : 256);
         long want = tiles >= 512 ? 1 : (1024 + tiles - 1) / tiles;
+        // tall-K on the 64-tile (the soft embedding, 105 tiles x K = 20000): ~5 blocks per CU measured better than 4
+        // (inside the step: split 12 or 16 -> 2.98 ms, split 10 -> 3.00 ms)
+        if (bt == 64 && d->K >= 4096 && tiles < 512) want = (1280 + tiles - 1) / tiles;
         if (few && want > 16) want = 16;
         const long max_by_k = d->K / min_k;
         if (want > max_by_k) want = max_by_k;
