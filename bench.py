@@ -239,7 +239,7 @@ def main():
         # the committed rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py; FETCH_SIZE and WRITE_SIZE in
         # separate runs, corrected for gfx950 as MI355X_MICROARCH.md prescribes), averaged over the symbol's launches
         traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        tp = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
         if os.path.exists(tp) and args.workload == "cfg2" and args.compute == "f32":
             with open(tp) as f:
                 tj = json.load(f)
@@ -250,7 +250,7 @@ def main():
                     tot_n += v["launches"]
             if tot_n:
                 traffic = tot_b / tot_n
-                traffic_src = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc, %d launches of this symbol)" % tot_n
+                traffic_src = "profiles/r03_pmc_traffic.json (rocprofv3 --pmc, %d launches of this symbol)" % tot_n
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         ms_step = 1e3 * elapsed / args.steps
         gemm_flops = sum(v[2] for v in summary["by_sym"].values()) / passes

@@ -432,16 +432,19 @@ struct Col2imRow {
 };
 // dx[(b*T + t), e] = beta * dx + sum_w sum_k dcols_w[(b, t-k), k*E + e] for t < L, (beta * dx +) 0 for L <= t < T (the
 // soft embedding's last timestep is dropped, cgn.py:1108); rowdot[b*T + t] = sum_e dx[.., e] * other[.., e] (the
-// softmax Jacobian's  sum_v p_v dp_v  of the fused backward epilogue, cgn.py:1103-1106 reversed). One wave per row.
-__global__ __launch_bounds__(256) void col2im_rowdot_kernel(const Col2imRow g, int B, int L, int T, int E, float beta,
-                                                            float* __restrict__ dx, const float* __restrict__ other,
-                                                            long ldo, float* __restrict__ rowdot) {
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= B * T) return;  // (whole waves)
+// softmax Jacobian's  sum_v p_v dp_v  of the fused backward epilogue, cgn.py:1103-1106 reversed). One workgroup per row,
+// one thread per element (all of an element's window loads in flight at once; a wave-per-row walk over e was a chain
+// of L2 round trips: 16 us against col2im's 6), the row's dot product through LDS.
+constexpr int C2R_MAX_WAVES = 16;
+__global__ __launch_bounds__(64 * C2R_MAX_WAVES) void col2im_rowdot_kernel(const Col2imRow g, int B, int L, int T, int E,
+                                                                            float beta, float* __restrict__ dx,
+                                                                            const float* __restrict__ other, long ldo,
+                                                                            float* __restrict__ rowdot) {
+    __shared__ float red[C2R_MAX_WAVES];
+    const int r = blockIdx.x;
     const int b = r / T, t = r % T;
     float dot = 0.f;
-    for (int e = lane; e < E; e += 64) {
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
         float acc = 0.f;
         if (t < L) {
             for (int j = 0; j < g.n; ++j) {
@@ -467,7 +470,14 @@ __global__ __launch_bounds__(256) void col2im_rowdot_kernel(const Col2imRow g, i
         dot += acc * other[(long)r * ldo + e];
     }
     dot = wave_sum(dot);
-    if (lane == 0) rowdot[r] = dot;
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[wave] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int w = 0; w < nw; ++w) s += red[w];  // fixed order
+        rowdot[r] = s;
+    }
 }
 
 }  // namespace
@@ -545,15 +555,16 @@ extern "C" int cgn_conv_col2im_rowdot_f32(void* stream, int32_t n, const float* 
                                           const float* other, int64_t ldo, float* rowdot) {
     CGN_CHECK_ARG(n >= 1 && n <= 8 && dcols && K && B > 0 && L > 0 && T >= L && E > 0);
     CGN_CHECK_ARG(dx && other && rowdot && ldo >= E);
-    CGN_CHECK_ARG((long)B * T < (1L << 31) / 4);
+    CGN_CHECK_ARG((long)B * T < (1L << 31));
     Col2imRow g;
     for (int i = 0; i < n; ++i) {
         CGN_CHECK_ARG(dcols[i] && K[i] >= 1 && K[i] <= L);
         g.dcols[i] = dcols[i]; g.K[i] = K[i];
     }
     g.n = n;
-    hipLaunchKernelGGL(col2im_rowdot_kernel, dim3(cgn_cdiv((long)B * T, 4)), dim3(256), 0, S_(stream), g, B, L, T, E, beta,
-                       dx, other, (long)ldo, rowdot);
+    const int nt = 64 * (cgn_cdiv(E, 64) < C2R_MAX_WAVES ? cgn_cdiv(E, 64) : C2R_MAX_WAVES);
+    hipLaunchKernelGGL(col2im_rowdot_kernel, dim3(B * T), dim3(nt), 0, S_(stream), g, B, L, T, E, beta, dx, other, (long)ldo,
+                       rowdot);
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }

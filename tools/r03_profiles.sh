@@ -19,7 +19,8 @@ timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/fetch"
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/write" -o w -- python3 "$R/bench.py" --eager --no-cpu-baseline --steps 5 --warmup 2 > "$O/write.log" 2>&1 || { echo "write pass failed"; tail -5 "$O/write.log"; exit 1; }
 python3 "$R/tools/pmc_traffic.py" "$O/fetch" "$O/write" "$O/pmc_traffic.json" > "$O/pmc_traffic.txt" 2>&1
 timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d "$O/mfma" -o m -- python3 "$R/bench.py" --eager --no-cpu-baseline --steps 5 --warmup 2 > "$O/mfma.log" 2>&1 || { echo "mfma pass failed"; tail -5 "$O/mfma.log"; exit 1; }
-python3 "$R/tools/pmc_mfma.py" "$O/mfma" "$O/mfma_busy.txt" > /dev/null 2>&1
+MS=$(python3 -c "import json; print(json.loads(open('$O/bench_line.json').read().strip().splitlines()[-1])['ms_per_step'])")
+python3 "$R/tools/pmc_mfma.py" "$O/mfma" "$O/mfma_busy.txt" 7 "$MS" > /dev/null 2>&1
 find "$O" -name "*counter_collection.csv" -delete
 head -12 "$O/pmc_traffic.txt"; head -14 "$O/mfma_busy.txt"; cat "$O"/bench_line*.json | python3 -c "
 import sys, json
