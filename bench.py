@@ -36,7 +36,11 @@ BATCH, SEQ = 64, 20
 CFG4 = dict(CFG2, max_seq_len=40, word_vocab_size=50000, encoder_rnn_size=1024, decoder_rnn_size=1024)
 WORKLOADS = {"cfg2": (CFG2, 64, 20), "cfg4": (CFG4, 256, 40)}
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 peak (~2.5 PF), --compute bf16 only
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 peak (~2.5 PF)
+# An X6 product (fp32 operands split exactly into three bf16 terms, six partial bf16 MFMA products, fp32 accumulation:
+# include/cgn_hip.h CGN_COMPUTE_F32X6) executes 6 bf16 MFMA FLOPs per algorithmic fp32 FLOP: its MFMA roof in
+# algorithmic FLOPs is the bf16 peak / 6
+X6_MFMA_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 
 
 def make_config(Config, cfgd=None):
@@ -102,11 +106,18 @@ def gemm_symbol(sym):
     """Kernel symbol of a product from ops.GEMM_PROFILE's key (csrc/gemm_core.h gemm_kernel's template arguments)."""
     bt, a_kc, b_kc, vec, exp, smb, bf16 = sym
     b = lambda v: "true" if v else "false"  # noqa: E731
-    kstep = (16 if bt == 128 else 32) * (2 if bf16 else 1)
     # vec: bits 0/1 = 16-byte loads on A/B (the template's VEC), bits 2.. = fast K addressing mode (the template's FK)
-    # bit 4 = A stored as bf16 (the template's A16)
+    # bit 4 = A stored as bf16 (the template's A16), bit 5 = the X6 kernel ran (three-term bf16 split of fp32 operands)
+    if is_x6(sym):
+        return "cgn_gemm::gemm_kernel<%d, %s, %s, %d, %s, 2, %d, %s, true, %d, false, true>" % (
+            bt, b(a_kc), b(b_kc), vec & 3, b(exp), 16 if bt == 128 else 32, b(smb), (vec >> 2) & 3)
+    kstep = (16 if bt == 128 else 32) * (2 if bf16 else 1)
     return "cgn_gemm::gemm_kernel<%d, %s, %s, %d, %s, 2, %d, %s, %s, %d, %s>" % (
         bt, b(a_kc), b(b_kc), vec & 3, b(exp), kstep, b(smb), b(bf16), (vec >> 2) & 3, b(vec & 16))
+
+
+def is_x6(sym):
+    return bool(sym[3] & 32)
 
 
 def main():
@@ -235,6 +246,11 @@ def main():
         # the roofline kernel = the symbol the step spends the most time in
         sym, (launches, ms, flops) = max(summary["by_sym"].items(), key=lambda kv: kv[1][1])
         name = gemm_symbol(sym)
+        if args.compute == "f32" and is_x6(sym):
+            peak_k, peak_note = X6_MFMA_PEAK_TFLOPS, ("dense bf16 MFMA peak / 6: the kernel forms an fp32-accurate product "
+                                                      "from six partial bf16 MFMA products (X6)")
+        else:
+            peak_k, peak_note = peak, ("dense fp32 MFMA peak" if args.compute == "f32" else "dense bf16 MFMA peak")
         # HBM bytes per launch of that symbol: PMC counters cannot be read from inside the run, so the figure comes from
         # the committed rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py; FETCH_SIZE and WRITE_SIZE in
         # separate runs, corrected for gfx950 as MI355X_MICROARCH.md prescribes), averaged over the symbol's launches
@@ -267,14 +283,19 @@ def main():
                                       "z 64, " if args.workload == "cfg2" else
                                       "BASELINE configs[3] SHAPES (stress, not the metric's workload): vocab 50k, "
                                       "seq len 40, batch 256/GPU, hidden 1024, z 64, ")
-                                   + ("fp32" if args.compute == "f32" else "OPTIONAL bf16 mode (bf16 MFMA operands, fp32 "
+                                   + (("fp32 (operands, accumulation, storage; products on the %s)" % (
+                                       "bf16 matrix pipe as exact three-term operand splits, X6: fp32 accuracy, "
+                                       "include/cgn_hip.h CGN_COMPUTE_F32X6" if ops.GEMM_X6 else "fp32 MFMA"))
+                                      if args.compute == "f32" else "OPTIONAL bf16 mode (bf16 MFMA operands, fp32 "
                                       "accumulation; logits / dlogits %s; everything else fp32 in memory; not the "
                                       "metric's fp32 configuration)" % ("held in bf16" if ops.BF16_STORAGE else "fp32"))
                                    + ", calc_z_loss=%s" % args.z_loss,
                        "global_batch": world * BATCH, "seq_len": SEQ, "parallelism": "dp%d" % world,
                        "launch": launch},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak_k, "unit": "TFLOP/s",
+                         "frac": achieved / peak_k, "peak_is": peak_note,
+                         "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS if args.compute == "f32" else None,
+                         "traffic": traffic,
                          "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
                          "kernel": name + " (the GEMM kernel symbol with the most time in the step: %.0f us of %.0f us "
                                           "per step)" % (1e3 * ms / passes, 1e3 * ms_step),
@@ -287,11 +308,12 @@ def main():
                                    + ("instrumented eager pass after the timed graph replays" if graph_timing else
                                       "inside the timed region")},
             # all MFMA work of one step (every GEMM product + the grouped convolution products + the LSTM recurrences)
-            # against the step time: the fraction of the fp32 MFMA peak the WHOLE step sustains
+            # against the step time: algorithmic fp32 FLOPs per second over the fp32 MFMA peak (with the X6 products on
+            # the bf16 pipe this is a rate relative to what fp32 MFMAs could reach, not a pipe occupancy)
             "step_mfma": {"gflop_per_step": step_flops / 1e9, "gemm_gflop": gemm_flops / 1e9,
                           "grouped_gflop": summary["group_flops"] / 1e9, "lstm_gflop": summary["lstm_flops"] / 1e9,
                           "achieved_tflops": step_flops / (ms_step * 1e-3) / 1e12,
-                          "utilisation": step_flops / (ms_step * 1e-3) / 1e12 / peak,
+                          "utilisation": step_flops / (ms_step * 1e-3) / 1e12 / peak, "utilisation_peak_tflops": peak,
                           "gemm_kernel_ms_per_step": sum(v[1] for v in summary["by_sym"].values()) / passes},
         }
         if extra:
@@ -315,6 +337,7 @@ def main():
         with open(path, "w") as f:
             f.write("# per-shape table of the step's GEMM products (%s, %s): HIP events directly around each MFMA kernel\n"
                     "# launch (split-K reduce launches excluded), %d instrumented steps; step time %.3f ms\n"
+                    "# frac = TFLOP/s over the kernel's MFMA roof: fp32 MFMA 157.3, X6 kernels (<..., true, FK, false, true>) bf16 peak / 6 = 416.7\n"
                     "# model = steady-state rate (0.92 | 0.86 of peak at 4096^3) x balance (tiles/CU over its ceiling, %d CUs)\n"
                     "#         x pad (M*N over the tile grid's area) x kshare (K steps per tile / (K steps + 8 | 4 of fixed cost))\n" %
                     (args.workload, args.compute, passes, ms_step, cus))
@@ -329,8 +352,10 @@ def main():
                 name = gemm_symbol(sym).replace("cgn_gemm::", "")
                 m = re.match(r"gemm_(?:group_)?kernel<(\d+)", name)
                 bt = int(m.group(1)) if m else 64
-                bf = args.compute == "bf16"  # (the model's constants are fp32 measurements: no model column then)
-                bk = (16 if bt == 128 else 32) * (2 if bf else 1)
+                x6 = args.compute == "f32" and is_x6(sym)
+                pk = X6_MFMA_PEAK_TFLOPS if x6 else peak
+                bf = args.compute == "bf16" or x6  # (the model's constants are fp32-MFMA measurements: no model column then)
+                bk = (16 if bt == 128 else 32) * (2 if args.compute == "bf16" else 1)
                 tm, tn = math.ceil(M / bt), math.ceil(N / bt)
                 tiles = tm * tn * max(sk, 1)
                 per_cu = tiles / cus
@@ -340,13 +365,14 @@ def main():
                 kshare = ksteps / (ksteps + (8 if bt == 128 else 4))
                 model = (0.92 if bt == 128 else 0.86) * bal * pad * kshare
                 f.write("%-62s %2d %6d %6d %6d %5.1f %8.1f %8.1f %6.3f | %6d %7.2f %5.2f %5.2f %6.2f %6.2f\n" % (
-                    name, sk, M, N, K, cnt / passes, us, tf, tf / peak, tiles, per_cu, bal, pad, kshare,
+                    name, sk, M, N, K, cnt / passes, us, tf, tf / pk, tiles, per_cu, bal, pad, kshare,
                     model if not bf else float("nan")))
             f.write("# per symbol\n")
             for sym, (cnt, t, fl) in sorted(summary["by_sym"].items(), key=lambda kv: -kv[1][1]):
+                pk = X6_MFMA_PEAK_TFLOPS if (args.compute == "f32" and is_x6(sym)) else peak
                 f.write("%-62s launches/step %5.1f  us/step %8.1f  TFLOP/s %7.1f  frac %5.3f\n" %
                         (gemm_symbol(sym).replace("cgn_gemm::", ""), cnt / passes, 1e3 * t / passes, fl / t / 1e9,
-                         fl / t / 1e9 / peak))
+                         fl / t / 1e9 / pk))
             f.write("# all products: %.1f us per step\n" % (1e3 * tot))
 
     def check_lstm():

@@ -54,6 +54,7 @@ typedef struct cgn_axis {
 
 #define CGN_COMPUTE_F32 0
 #define CGN_COMPUTE_BF16 1
+#define CGN_COMPUTE_F32X6 2 /* fp32 result from the bf16 matrix pipe: see cgn_gemm_desc.compute */
 
 /* cgn_gemm_desc.storage bits: bf16 STORAGE of the logits-sized tensors in the optional bf16 mode (compute must be
  * CGN_COMPUTE_BF16). Everything not named here stays fp32 in memory. */
@@ -99,7 +100,13 @@ typedef struct cgn_gemm_desc {
     /* Operand type of the product (the optional bf16 mode): CGN_COMPUTE_F32 = exact fp32 (v_mfma_f32_32x32x2_f32);
      * CGN_COMPUTE_BF16 = A (after a_transform) and B are rounded to bf16 (nearest-even) as they are staged into LDS
      * and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation. Memory operands, bias, epilogue, split-K
-     * slabs and C stay fp32 in both modes unless `storage` names a tensor. */
+     * slabs and C stay fp32 in both modes unless `storage` names a tensor.
+     * CGN_COMPUTE_F32X6 = fp32 accuracy on the bf16 pipe: every operand element is split EXACTLY into three bf16 terms
+     * (x = p0 + p1 + p2, round-to-nearest terms, error-free) as it is staged into LDS, and the product is formed as six
+     * partial bf16 MFMA products a0b0 + a0b1 + a1b0 + a0b2 + a1b1 + a2b0 with fp32 accumulation; the three dropped
+     * terms are below 2^-23 |a b| per product, the size of fp32's own rounding. 2.67x less matrix-pipe time than the
+     * fp32 MFMA. Products whose layout has no such variant (scalar loads, two-level K axes other than the history
+     * walk, grouped launches) run the CGN_COMPUTE_F32 kernel; operands with +-inf give NaN (inf - inf in the split). */
     int32_t compute;
     int32_t storage; /* CGN_STORE_* bits, 0 = every tensor fp32 */
     /* CGN_EPI_SOFTMAX_BWD with CGN_STORE_C_BF16 only, nullable: a transposed bf16 copy of C, c_t[n * ld_ct + m] — the

@@ -1,6 +1,8 @@
 // MFMA GEMM for gfx950, host side: C = epilogue(alpha * A·B + beta*C + bias). Descriptor validation, the tile / split-K
 // plan and the entry points cgn_gemm_f32 / cgn_gemm_group_f32 / cgn_gemm_plan. The device templates are in gemm_core.h;
 // this file instantiates them for exact-fp32 operands (v_mfma_f32_32x32x2_f32), gemm_bf16.hip for bf16 operands.
+#include <cstdlib>
+
 #include "gemm_core.h"
 
 using namespace cgn_gemm;
@@ -31,7 +33,11 @@ int g_stages = 0;  // 0 = default; tools/gemm_bench.py overrides it through cgn_
 int g_order = 2;   // tile-order experiment knob (cgn_debug_set_stages bits 4..7); 2 = default
 
 // Tile / split-K heuristic: MI355X has 256 CUs and this kernel fits ~3-4 blocks per CU; aim for >= ~512 blocks.
-int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out) {
+// x6: the product will run an X6 kernel (run_gemm / cgn_gemm_plan know after prepare_gemm)
+int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out, bool x6 = false) {
+    static const int x6_tile = getenv("CGN_X6_TILE") ? atoi(getenv("CGN_X6_TILE")) : 0;       // experiment knobs
+    static const int x6_blocks = getenv("CGN_X6_BLOCKS") ? atoi(getenv("CGN_X6_BLOCKS")) : 1024;
+    static const int x6_mink = getenv("CGN_X6_MINK") ? atoi(getenv("CGN_X6_MINK")) : 512;
     // Measured on MI355X (tools/gemm_bench.py): the kernel needs >= ~4 blocks per CU to keep the MFMA pipes fed, the
     // 128-tile is the better choice once there are enough of them, and tall-K products want K split across blocks.
     const long t128 = (long)cgn_cdiv(d->M, 128) * cgn_cdiv(d->N, 128);
@@ -52,6 +58,7 @@ int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out
             const double a64 = (double)cgn_cdiv(d->M, 64) * 64.0 * (double)cgn_cdiv(d->N, 64) * 64.0;
             if (0.86 / a64 > 1.05 * 0.92 / a128) bt = 64;
         }
+        if (x6 && x6_tile == 128 && d->M >= 256 && d->N >= 256) bt = 128;
     }
     const long tiles = bt == 128 ? t128 : t64;
     if (splitk <= 0 && bt == 128 && d->K >= 4096) {  // tall-K only: a split of the K = 1344 dW_fc product (sk 2) won 11 %
@@ -81,8 +88,9 @@ int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out
         // handful of tiles (e2mu/e2logvar, d[z,c], the text-CNN windows) are pure latency chains of K/BK dependent
         // steps on one CU each: split them hard, whatever their FLOP count.
         const bool few = tiles < 64;
-        const int min_k = few ? 128 : (bt == 128 ? 512 : 256);
+        const int min_k = few ? 128 : (bt == 128 ? ((x6 && x6_tile == 128) ? x6_mink : 512) : 256);
         long want = tiles >= 512 ? 1 : (1024 + tiles - 1) / tiles;
+        if (x6 && bt == 128 && x6_tile == 128) want = tiles >= 384 ? 1 : (x6_blocks + tiles / 2) / tiles;
         // tall-K on the 64-tile (the soft embedding, 105 tiles x K = 20000): ~5 blocks per CU measured better than 4
         // (inside the step: split 12 or 16 -> 2.98 ms, split 10 -> 3.00 ms)
         if (bt == 64 && d->K >= 4096 && tiles < 512) want = (1280 + tiles - 1) / tiles;
@@ -112,6 +120,9 @@ int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out
 
 }  // namespace
 
+static int prepare_gemm(const cgn_gemm_desc* d, GemmParams& p, bool& a_kc, bool& b_kc);
+static bool x6_variant_exists(const GemmParams& p, bool a_kc, bool b_kc);
+
 extern "C" void cgn_debug_set_stages(int v) {
     g_stages = v & 15;  // kept for ABI stability: the stage count is fixed at 2 since round 1
     g_order = (v >> 4) & 15;
@@ -123,7 +134,15 @@ extern "C" int cgn_gemm_plan(const cgn_gemm_desc* d, int32_t* tile, int32_t* spl
     CGN_CHECK_ARG(d && tile && splitk && a_kcontig && b_kcontig);
     CGN_CHECK_ARG(d->force_tile == 0 || d->force_tile == 64 || d->force_tile == 128);
     int bt, sk, kps;
-    const int rc = plan_gemm(d, &bt, &sk, &kps);
+    bool x6 = false;
+    if (d->compute == CGN_COMPUTE_F32X6) {
+        GemmParams p;
+        bool a_kc = false, b_kc = false;
+        const int rc0 = prepare_gemm(d, p, a_kc, b_kc);
+        if (rc0) return rc0;
+        x6 = d->M > 0 && d->N > 0 && x6_variant_exists(p, a_kc, b_kc);
+    }
+    const int rc = plan_gemm(d, &bt, &sk, &kps, x6);
     if (rc) return rc;
     *tile = bt; *splitk = sk;
     *a_kcontig = (d->a_k.stride == 1 || d->a_m.stride != 1) ? 1 : 0;
@@ -149,7 +168,7 @@ static int prepare_gemm(const cgn_gemm_desc* d, GemmParams& p, bool& a_kc, bool&
     if (d->epilogue == CGN_EPI_SOFTMAX_BWD)
         CGN_CHECK_ARG(d->ep_logits && d->ep_lse && d->ep_rowdot && d->ep_target && d->ep_ld >= d->N);
     CGN_CHECK_ARG(d->force_tile == 0 || d->force_tile == 64 || d->force_tile == 128);
-    CGN_CHECK_ARG(d->compute == CGN_COMPUTE_F32 || d->compute == CGN_COMPUTE_BF16);
+    CGN_CHECK_ARG(d->compute == CGN_COMPUTE_F32 || d->compute == CGN_COMPUTE_BF16 || d->compute == CGN_COMPUTE_F32X6);
     const bool a16 = (d->storage & CGN_STORE_A_BF16) != 0, c16 = (d->storage & CGN_STORE_C_BF16) != 0;
     const bool ep16 = (d->storage & CGN_STORE_EP_BF16) != 0;
     CGN_CHECK_ARG((d->storage & ~(CGN_STORE_A_BF16 | CGN_STORE_C_BF16 | CGN_STORE_EP_BF16)) == 0);
@@ -218,6 +237,14 @@ static int prepare_gemm(const cgn_gemm_desc* d, GemmParams& p, bool& a_kc, bool&
     return CGN_OK;
 }
 
+// mirrors launch_x6_t (gemm_core.h): the layouts the X6 translation unit instantiates
+static bool x6_variant_exists(const GemmParams& p, bool a_kc, bool b_kc) {
+    if (!(p.a_vec && p.b_vec) || p.fastk == 0 || p.a16 || p.c16 || p.ep16) return false;
+    if (p.fastk == 2) return p.a_transform == CGN_ATRANS_NONE;
+    if (p.a_transform == CGN_ATRANS_EXP) return a_kc && !b_kc;
+    return !(!a_kc && b_kc);
+}
+
 static int run_gemm(void* stream, const cgn_gemm_desc* d, hipEvent_t ev_start, hipEvent_t ev_stop,
                     int32_t* vec_mode = nullptr) {
     GemmParams p;
@@ -227,9 +254,10 @@ static int run_gemm(void* stream, const cgn_gemm_desc* d, hipEvent_t ev_start, h
         if (rc) return rc;
     }
     if (d->M == 0 || d->N == 0) return CGN_OK;
+    const bool x6 = d->compute == CGN_COMPUTE_F32X6 && x6_variant_exists(p, a_kc, b_kc);
     int bt, splitk, kps;
     {
-        const int rc = plan_gemm(d, &bt, &splitk, &kps);
+        const int rc = plan_gemm(d, &bt, &splitk, &kps, x6);
         if (rc) return rc;
     }
     if (p.c16 && splitk > 1) {  // a bf16 C is written by the product kernel itself: no slabs, no reduce pass
@@ -245,12 +273,14 @@ static int run_gemm(void* stream, const cgn_gemm_desc* d, hipEvent_t ev_start, h
 
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)tiles, (unsigned)splitk);
-    if (vec_mode) *vec_mode = (p.a_vec ? 1 : 0) | (p.b_vec ? 2 : 0) | (p.fastk << 2) | (p.a16 ? 16 : 0);
+    if (vec_mode) *vec_mode = (p.a_vec ? 1 : 0) | (p.b_vec ? 2 : 0) | (p.fastk << 2) | (p.a16 ? 16 : 0) | (x6 ? 32 : 0);
     if (ev_start && hipEventRecord(ev_start, s) != hipSuccess) return CGN_ERR_HIP_BASE + (int)hipGetLastError();
     if (p.a16)
         launch_gemm_a16(p, bt, b_kc, grid, s);
     else if (d->compute == CGN_COMPUTE_BF16)
         launch_gemm_bf16ops(p, bt, a_kc, b_kc, grid, s);
+    else if (x6)
+        launch_gemm_x6(p, bt, a_kc, b_kc, grid, s);
     else
         launch_gemm_f32ops(p, bt, a_kc, b_kc, grid, s);
     CGN_LAUNCH_CHECK();

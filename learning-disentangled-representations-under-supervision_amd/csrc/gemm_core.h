@@ -132,6 +132,21 @@ __device__ __forceinline__ u32x2 pack_bf16x4(const f32x4& v) {
     return w;
 }
 
+// X6: the exact three-way split of fp32 operands, x = p0 + p1 + p2 with every term a bf16 (round to nearest: p0 = bf16(x),
+// p1 = bf16(x - p0), p2 = x - p0 - p1; both differences are exact in fp32 and the last one has at most 8 significant bits,
+// so the sum is x bit for bit). A product then runs on the bf16 matrix pipe as SIX partial products
+//   a.b ~= a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0),    dropped: a1 b2 + a2 b1 + a2 b2 <= 2^-23 |a b|
+// accumulated in fp32: the accuracy of an fp32 product (unit roundoff 2^-24) at 6 x 32 instead of 8 x 64 matrix-pipe
+// cycles per 32x32x16 block (2.67x less MFMA time). Here: two elements at a time, packed pairs per term.
+__device__ __forceinline__ void split3_pk(float a, float b, unsigned& w0, unsigned& w1, unsigned& w2) {
+    w0 = pack_bf16x2(a, b);
+    float ra = a - __builtin_bit_cast(float, w0 << 16), rb = b - __builtin_bit_cast(float, w0 & 0xffff0000u);
+    w1 = pack_bf16x2(ra, rb);
+    ra -= __builtin_bit_cast(float, w1 << 16);
+    rb -= __builtin_bit_cast(float, w1 & 0xffff0000u);
+    w2 = pack_bf16x2(ra, rb);
+}
+
 // Operand tile loader. The tile is ROWS (m or n index) x BK (k index); its LDS image is row-major [ROWS][LDK] with
 // LDK = BK + 4 floats (144-byte rows): the MFMA loop reads a lane's 4 consecutive k of one row with ONE ds_read_b128
 // (rows 144 B apart put 16 consecutive rows on 16 different 16-byte slots of the 256-byte bank row: conflict-free),
@@ -144,13 +159,20 @@ __device__ __forceinline__ u32x2 pack_bf16x4(const f32x4& v) {
 // SRC16: the operand is a k-contiguous bf16 matrix addressed in 4-byte words (BK, strides and k positions count WORDS =
 // pairs of k; BF is false: a loaded quad of words IS 8 consecutive bf16 of the bf16 LDS image, whose row stride
 // (BK_elements + 8) / 2 words equals this loader's BK + 4). Only the exp transform looks inside a word.
-template <int ROWS, bool KC, int BK, int S, bool VEC, bool EXP, bool BF, int FK = 0, bool SRC16 = false>
+// X6 (with BF): the operand is split into three bf16 terms at staging (split3_pk); the LDS image is three bf16 planes,
+// PLANE words apart. A k-contiguous operand uses the bf16 row-major image per plane; a row-contiguous one a
+// "pair-major" image [BK/2][ROWS] of 4-byte words (the two consecutive k of one row): the lane's quad of rows of one k
+// pair is ONE conflict-free 16-byte write per plane, and the MFMA loop reads a lane's 8 k with four 4-byte reads, lanes
+// along the rows (the row-major bf16 image needs transposing 4-byte writes, 8-way bank-conflicted).
+template <int ROWS, bool KC, int BK, int S, bool VEC, bool EXP, bool BF, int FK = 0, bool SRC16 = false, bool X6 = false>
 struct TileLoader {
+    static_assert(!X6 || (BF && VEC && !SRC16), "X6: fp32 operand, 16-byte loads, bf16 planes in LDS");
     static_assert(!SRC16 || (KC && VEC && !BF), "bf16 storage: k-contiguous, 16-byte loads, raw copy into the bf16 image");
     static_assert(!FK || VEC, "fast K addressing is built for the 16-byte load paths");
     static_assert(FK != 2 || !KC, "the two-level fast form exists for row-contiguous operands");
     // LDS row stride in 4-byte words: BK + 4 floats, or (BF) BK + 8 bf16: 16 bytes of padding either way
     static constexpr int LDK = BF ? (BK + 8) / 2 : BK + 4;
+    static constexpr int PLANE = ROWS * LDK;     // X6: words between the planes of the three terms
     static constexpr int QUADS = ROWS * BK / 4;  // 4-k chunks per tile
     static constexpr int PER = QUADS / NT;       // chunks per thread
     static_assert(QUADS % NT == 0, "tile/threads mismatch");
@@ -348,10 +370,44 @@ struct TileLoader {
                     if constexpr (MASK) x = (rok[i] && k + j < kend) ? x : 0.f;
                     v[j] = x;
                 }
-                if constexpr (BF)
+                if constexpr (X6) {
+                    unsigned t0[2], t1[2], t2[2];
+                    split3_pk(v[0], v[1], t0[0], t1[0], t2[0]);
+                    split3_pk(v[2], v[3], t0[1], t1[1], t2[1]);
+                    const u32x2 w0 = {t0[0], t0[1]}, w1 = {t1[0], t1[1]}, w2 = {t2[0], t2[1]};
+                    float* d = dst + (r + i * RS) * LDK + q * 2;
+                    *reinterpret_cast<u32x2*>(d) = w0;
+                    *reinterpret_cast<u32x2*>(d + PLANE) = w1;
+                    *reinterpret_cast<u32x2*>(d + 2 * PLANE) = w2;
+                } else if constexpr (BF)
                     *reinterpret_cast<u32x2*>(dst + (r + i * RS) * LDK + q * 2) = pack_bf16x4(v);
                 else
                     *reinterpret_cast<f32x4*>(dst + (r + i * RS) * LDK + q * 4) = v;
+            }
+        } else if constexpr (VEC && X6) {
+            // pair-major planes [BK/2][ROWS]: word = (k, k+1) of one row
+            const int row = 4 * (tid % RQ);
+            const int kl = (tid / RQ) * KP;
+#pragma unroll
+            for (int j = 0; j < KP; j += 2) {
+                f32x4 lo = regs[st][j], hi = regs[st][j + 1];
+                if constexpr (MASK) {
+                    const bool k0ok = k0 + kl + j < kend, k1ok = k0 + kl + j + 1 < kend;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        lo[i] = (rok4[i] && k0ok) ? lo[i] : 0.f;
+                        hi[i] = (rok4[i] && k1ok) ? hi[i] : 0.f;
+                    }
+                }
+                unsigned t0[4], t1[4], t2[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) split3_pk(lo[i], hi[i], t0[i], t1[i], t2[i]);
+                const u32x4_t w0 = {t0[0], t0[1], t0[2], t0[3]}, w1 = {t1[0], t1[1], t1[2], t1[3]},
+                              w2 = {t2[0], t2[1], t2[2], t2[3]};
+                float* d = dst + ((kl + j) / 2) * ROWS + row;
+                *reinterpret_cast<u32x4_t*>(d) = w0;
+                *reinterpret_cast<u32x4_t*>(d + PLANE) = w1;
+                *reinterpret_cast<u32x4_t*>(d + 2 * PLANE) = w2;
             }
         } else if constexpr (VEC && !BF) {
             // k-major image [BK][ROWS]: the lane's quad (4 consecutive rows of one k) goes out as ONE 16-byte write, lanes
@@ -461,14 +517,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // SMB: the batched softmax-backward epilogue is compiled in (only the dlogits product's variant: inside the shared
 // variant its registers cost the vocabulary projection 10 %).
 template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK, bool SMB = false, bool BF = false,
-          int FK = 0, bool A16 = false>
+          int FK = 0, bool A16 = false, bool X6 = false>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, const int t) {
     static_assert(!A16 || (BF && A_KC && (VEC & 1)), "bf16-stored A: bf16 MFMA operands, k-contiguous, 16-byte loads");
+    static_assert(!X6 || (BF && !A16 && VEC == 3), "X6: fp32 operands in memory, three bf16 planes in LDS");
+    constexpr int NP = X6 ? 3 : 1;   // planes per operand image
     constexpr int TW = BT / 64;  // 32x32 accumulators per wave along each dim
     constexpr int LDK = BF ? (BK + 8) / 2 : BK + 4;  // LDS row stride (4-byte words) of both operand images
     // One LDS array (both operands, two buffers): keeps every carve offset explicit and 16-byte aligned.
-    constexpr int TILE = BT * LDK;  // floats per operand image
-    __shared__ __attribute__((aligned(16))) float lds[4 * TILE];
+    constexpr int TILE = BT * LDK;  // floats per operand image (per plane)
+    constexpr int OPI = NP * TILE;  // one operand's image
+    __shared__ __attribute__((aligned(16))) float lds[4 * OPI];
 
     int tile_m, tile_n;
     // the SHORTER tile axis runs fastest: tiles that are neighbours in the list (same XCD after the remap, resident
@@ -494,8 +553,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
     static_assert(!FK || VEC == 3, "fast K addressing needs 16-byte loads on both operands");
     // (FK == 2: only B's K axis is two-level.) A16: A's loader works in words, KA = 2 k per word
     constexpr int KA = A16 ? 2 : 1;
-    TileLoader<BT, A_KC, BK / KA, S, (VEC & 1) != 0, EXP, BF && !A16, (FK ? 1 : 0), A16> la;
-    TileLoader<BT, B_KC, BK, S, (VEC & 2) != 0, false, BF, FK> lb;
+    TileLoader<BT, A_KC, BK / KA, S, (VEC & 1) != 0, EXP, BF && !A16, (FK ? 1 : 0), A16, X6> la;
+    TileLoader<BT, B_KC, BK, S, (VEC & 2) != 0, false, BF, FK, false, X6> lb;
     la.init(p.am, m0, p.M, p.a_row_param);
     lb.init(p.bn, n0, p.N, nullptr);
     if constexpr (FK) {
@@ -541,7 +600,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
             lb.load(j, p.B, p.bk, kbeg + j * BK, kbeg, kend);
         }
         la.template store<true>(0, lds, kbeg / KA, kend / KA, a_scale);
-        lb.template store<true>(0, lds + TILE, kbeg, kend, 0.f);
+        lb.template store<true>(0, lds + OPI, kbeg, kend, 0.f);
         la.load(0, p.A, p.ak, (kbeg + S * BK) / KA, kbeg / KA, kend / KA);
         lb.load(0, p.B, p.bk, kbeg + S * BK, kbeg, kend);
     }
@@ -551,10 +610,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
     const int fk = lane >> 5;  // k-slice within the MFMA's k step
     constexpr int KB = BF ? 16 : 8;   // k per block of MFMAs
     constexpr int NBLK = BK / KB;     // blocks per K step
-    static_assert(NBLK >= 2 && NBLK % 2 == 0, "the fragment double buffer wraps at the step boundary");
+    static_assert(NBLK == 1 || NBLK % 2 == 0, "the fragment double buffer wraps at the step boundary");
     // fragment registers: [double buffer][tile index]; fp32: 4 consecutive k of one row = one ds_read_b128, bf16: 8 k
     typedef typename std::conditional<BF, bf16x8, f32x4>::type frag_t;
-    frag_t fa[2][TW], fb[2][TW];
+    frag_t fa[2][NP][TW], fb[2][NP][TW];
     // lane's fragment base inside an operand image (4-byte words)
     const int a_lane = (wm * (BT / 2) + fr) * LDK + 4 * fk;
     const int b_lane = (wn * (BT / 2) + fr) * LDK + 4 * fk;
@@ -563,35 +622,69 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
     constexpr bool A_KM = !A_KC && !BF, B_KM = !B_KC && !BF;
     const int a_lane_km = (4 * fk) * BT + wm * (BT / 2) + fr;
     const int b_lane_km = (4 * fk) * BT + wn * (BT / 2) + fr;
+    // X6, row-contiguous operand: pair-major planes [BK/2][BT] (TileLoader::store): word e of the lane's fragment is the
+    // pair (2e, 2e+1) of its 8 k = four 4-byte reads at the same lane offsets as the k-major fp32 image
+    constexpr bool A_PM = !A_KC && X6, B_PM = !B_KC && X6;
     auto read_frags = [&](const float* As_, const float* Bs_, int jb, int slot) {
         // block jb: k = jb*KB .. jb*KB+KB-1; lane half fk holds 4 (fp32) / 8 (bf16) consecutive k = 4 words either way
         constexpr int WPB = BF ? 8 : 8;  // words per block per row: fp32 8 floats; bf16 16 halves = 8 words
 #pragma unroll
-        for (int i = 0; i < TW; ++i) {
-            if constexpr (A_KM) {
+        for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) fa[slot][i][e] = As_[a_lane_km + (jb * 8 + e) * BT + i * 32];
-            } else {
-                fa[slot][i] = *reinterpret_cast<const frag_t*>(As_ + a_lane + i * 32 * LDK + jb * WPB);
+            for (int i = 0; i < TW; ++i) {
+                if constexpr (A_PM) {
+                    f32x4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = As_[pl * TILE + a_lane_km + (jb * 8 + e) * BT + i * 32];
+                    fa[slot][pl][i] = __builtin_bit_cast(frag_t, w);
+                } else if constexpr (A_KM) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fa[slot][pl][i][e] = As_[a_lane_km + (jb * 8 + e) * BT + i * 32];
+                } else {
+                    fa[slot][pl][i] = *reinterpret_cast<const frag_t*>(As_ + pl * TILE + a_lane + i * 32 * LDK + jb * WPB);
+                }
             }
-        }
 #pragma unroll
-        for (int j = 0; j < TW; ++j) {
-            if constexpr (B_KM) {
+            for (int j = 0; j < TW; ++j) {
+                if constexpr (B_PM) {
+                    f32x4 w;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) fb[slot][j][e] = Bs_[b_lane_km + (jb * 8 + e) * BT + j * 32];
-            } else {
-                fb[slot][j] = *reinterpret_cast<const frag_t*>(Bs_ + b_lane + j * 32 * LDK + jb * WPB);
+                    for (int e = 0; e < 4; ++e) w[e] = Bs_[pl * TILE + b_lane_km + (jb * 8 + e) * BT + j * 32];
+                    fb[slot][pl][j] = __builtin_bit_cast(frag_t, w);
+                } else if constexpr (B_KM) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fb[slot][pl][j][e] = Bs_[b_lane_km + (jb * 8 + e) * BT + j * 32];
+                } else {
+                    fb[slot][pl][j] = *reinterpret_cast<const frag_t*>(Bs_ + pl * TILE + b_lane + j * 32 * LDK + jb * WPB);
+                }
             }
         }
     };
-    auto mfma_block = [&](int slot) {
-        if constexpr (BF) {
+    // X6: six partial products per accumulator, term-major (the same accumulator comes round every TW*TW MFMAs; the
+    // 64-tile alternates its two chains), small terms first; terms [q0, q1) of the block in fragment slot `slot`
+    auto mfma_x6_terms = [&](int slot, int q0, int q1) {
+        constexpr int TA[6] = {0, 1, 2, 0, 1, 0}, TB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            if (q < q0 || q >= q1) continue;
 #pragma unroll
             for (int i = 0; i < TW; ++i)
 #pragma unroll
                 for (int j = 0; j < TW; ++j)
-                    acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot][i], fb[slot][j], acc[0][i][j], 0, 0, 0);
+                    acc[q % NC][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot][X6 ? TA[q] : 0][i],
+                                                                               fb[slot][X6 ? TB[q] : 0][j],
+                                                                               acc[q % NC][i][j], 0, 0, 0);
+        }
+    };
+    auto mfma_block = [&](int slot) {
+        if constexpr (X6) {
+            mfma_x6_terms(slot, 0, 6);
+        } else if constexpr (BF) {
+#pragma unroll
+            for (int i = 0; i < TW; ++i)
+#pragma unroll
+                for (int j = 0; j < TW; ++j)
+                    acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot][0][i], fb[slot][0][j], acc[0][i][j], 0, 0, 0);
         } else {
             // K order inside a block: lane half fk holds k = 4fk + e for the e-th MFMA (any permutation of k is legal as
             // long as A and B use the same one)
@@ -601,20 +694,47 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
                 for (int i = 0; i < TW; ++i)
 #pragma unroll
                     for (int j = 0; j < TW; ++j)
-                        acc[e % NC][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][i][e], fb[slot][j][e],
+                        acc[e % NC][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][0][i][e], fb[slot][0][j][e],
                                                                                  acc[e % NC][i][j], 0, 0, 0);
         }
     };
-    if (nk > 0) read_frags(lds, lds + TILE, 0, 0);
+    if (nk > 0) read_frags(lds, lds + OPI, 0, 0);
 
     // one K step; u = step index within the unrolled trip (compile-time after unrolling), MASK = masked LDS store
     auto k_step = [&](auto mask_tag, int u, int kt) {
         constexpr bool MASK = decltype(mask_tag)::value;
-        const float* As = lds + (u & 1) * 2 * TILE;
-        const float* Bs = As + TILE;
-        float* An = lds + ((u + 1) & 1) * 2 * TILE;
+        const float* As = lds + (u & 1) * 2 * OPI;
+        const float* Bs = As + OPI;
+        float* An = lds + ((u + 1) & 1) * 2 * OPI;
         const int st = (u + 1) % S;
         const int k1 = kbeg + (kt + 1) * BK;
+        if constexpr (NBLK == 1) {
+            // One block of MFMAs per K step (X6, 128-tile: 24 MFMAs = 768 matrix-pipe cycles per wave and step); the
+            // fragment slot alternates with the step. A wave issues in order, so its own staging work of the next tile
+            // (the three-way split: ~100 VALU instructions, 12 LDS writes, 4 global loads) is INTERLEAVED with the first
+            // five terms' MFMAs (7 issue slots under each 32-cycle MFMA): two resident blocks that run in lock step - both
+            // splitting, then both multiplying - halve the matrix pipe's duty (measured: 0.43). The last term's MFMAs
+            // sit behind the barrier and cover the round trip of the next tile's fragment reads.
+            constexpr int QA = 5;
+            la.template store<MASK>(st, An, k1 / KA, kend / KA, a_scale);
+            lb.template store<MASK>(st, An + OPI, k1, kend, 0.f);
+            la.load(st, p.A, p.ak, (k1 + S * BK) / KA, kbeg / KA, kend / KA);
+            lb.load(st, p.B, p.bk, k1 + S * BK, kbeg, kend);
+            mfma_x6_terms(u & 1, 0, QA);
+#pragma unroll
+            for (int g = 0; g < QA * TW * TW; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // VALU of the split
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // an LDS write
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // a global load
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            read_frags(An, An + OPI, 0, (u + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_x6_terms(u & 1, QA, 6);
+            return;
+        }
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb) {
             if (jb + 1 < NBLK) {
@@ -623,7 +743,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
             }
             if (jb == 0) {
                 la.template store<MASK>(st, An, k1 / KA, kend / KA, a_scale);
-                lb.template store<MASK>(st, An + TILE, k1, kend, 0.f);
+                lb.template store<MASK>(st, An + OPI, k1, kend, 0.f);
                 la.load(st, p.A, p.ak, (k1 + S * BK) / KA, kbeg / KA, kend / KA);
                 lb.load(st, p.B, p.bk, k1 + S * BK, kbeg, kend);
             }
@@ -632,7 +752,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
                 // scheduler hoists the MFMAs above the barrier and the wave meets the LDS round trip with an empty pipe)
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();
-                read_frags(An, An + TILE, 0, 0);  // block 0 of the next tile: lands under this block's MFMAs
+                read_frags(An, An + OPI, 0, 0);  // block 0 of the next tile: lands under this block's MFMAs
                 __builtin_amdgcn_sched_barrier(0);
             }
             mfma_block(jb & 1);
@@ -669,7 +789,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
         // leaves as 16-byte row stores; the optional transposed copy ct is staged the same way from the packed values.
         static_assert(BT == 128, "the staged bf16 epilogue is laid out for the 128-tile (4 waves x 64x64)");
         constexpr int RS = 72;  // staging row stride in bf16 elements (144 B: 16-byte aligned rows)
-        static_assert(4 * 64 * RS * 2 <= 4 * TILE * 4, "staging images must fit the operand buffers");
+        static_assert(4 * 64 * RS * 2 <= 4 * OPI * 4, "staging images must fit the operand buffers");
         unsigned short* stage = reinterpret_cast<unsigned short*>(lds) + wave * (64 * RS);
         const float inv_tau = p.dyn ? p.dyn[0] : p.ep_inv_tau;
         const float ce_scale = p.dyn ? p.dyn[1] : p.ep_ce_scale;
@@ -778,7 +898,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
         if constexpr (BT == 128) {
             if (p.epilogue == CGN_EPI_LINEAR) {  // the vocabulary projection: staged through LDS like the fused epilogue
                 constexpr int RS = 72;
-                static_assert(4 * 64 * RS * 2 <= 4 * TILE * 4, "staging images must fit the operand buffers");
+                static_assert(4 * 64 * RS * 2 <= 4 * OPI * 4, "staging images must fit the operand buffers");
                 unsigned short* stage = reinterpret_cast<unsigned short*>(lds) + wave * (64 * RS);
                 __syncthreads();  // every wave is done with the operand images
 #pragma unroll
@@ -896,8 +1016,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
     }
 }
 
+// (X6, 128-tile: BK = 16, 72 KB of LDS: two blocks per CU, whose waves cover each other's staging work)
 template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK = (BT == 128 ? 16 : 32), bool SMB = false,
-          bool BF = false, int FK = 0, bool A16 = false>
+          bool BF = false, int FK = 0, bool A16 = false, bool X6 = false>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
     // Work item = (K split, tile). Default (order 2): the XCD remap runs over the tile list, the shorter tile axis
     // fastest (gemm_tile: neighbouring tiles share a panel of the operand that spans the long axis). Orders 0/1 remap over the whole (split, tile) list so that an XCD
@@ -915,7 +1036,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
         split = w / ntiles;
         t = w - split * ntiles;
     }
-    gemm_tile<BT, A_KC, B_KC, VEC, EXP, S, BK, SMB, BF, FK, A16>(p, split, t);
+    gemm_tile<BT, A_KC, B_KC, VEC, EXP, S, BK, SMB, BF, FK, A16, X6>(p, split, t);
 }
 
 // Grouped launch: up to GROUP_MAX independent products (same kernel variant) in ONE launch; block b works on the
@@ -1076,6 +1197,40 @@ void launch_a16_t(const GemmParams& p, bool b_kc, dim3 grid, hipStream_t s) {
     }
 }
 
+// X6 variants (gemm_x6.hip): fp32 operands with 16-byte loads and fast K addressing only; false = no such variant (the
+// caller runs the fp32-MFMA kernel instead)
+template <int BT>
+bool launch_x6_t(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
+    constexpr int BK = BT == 128 ? 16 : 32;
+    if (!(p.a_vec && p.b_vec) || p.fastk == 0 || p.a16 || p.c16 || p.ep16) return false;
+    const bool ex = p.a_transform == CGN_ATRANS_EXP;
+    if (p.fastk == 2) {
+        if (ex) return false;
+        hipLaunchKernelGGL((gemm_kernel<BT, false, false, 3, false, 2, BK, false, true, 2, false, true>), grid, dim3(NT), 0, s, p);
+        return true;
+    }
+    if (ex) {
+        if (!a_kc || b_kc) return false;  // (the soft embedding: exp(logits) . E)
+        hipLaunchKernelGGL((gemm_kernel<BT, true, false, 3, true, 2, BK, false, true, 1, false, true>), grid, dim3(NT), 0, s, p);
+        return true;
+    }
+    if constexpr (BT == 128) {
+        if (a_kc && b_kc && p.epilogue == CGN_EPI_SOFTMAX_BWD && p.splitk == 1) {
+            hipLaunchKernelGGL((gemm_kernel<BT, true, true, 3, false, 2, BK, true, true, 1, false, true>), grid, dim3(NT), 0, s, p);
+            return true;
+        }
+    }
+    if (a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_kernel<BT, true, true, 3, false, 2, BK, false, true, 1, false, true>), grid, dim3(NT), 0, s, p);
+    else if (a_kc && !b_kc)
+        hipLaunchKernelGGL((gemm_kernel<BT, true, false, 3, false, 2, BK, false, true, 1, false, true>), grid, dim3(NT), 0, s, p);
+    else if (!a_kc && !b_kc)
+        hipLaunchKernelGGL((gemm_kernel<BT, false, false, 3, false, 2, BK, false, true, 1, false, true>), grid, dim3(NT), 0, s, p);
+    else
+        return false;
+    return true;
+}
+
 template <int VEC, bool BF, int FK>
 void launch_group_vk(const GemmGroup& g, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s) {
     constexpr int BK = bk_of<64, BF>();
@@ -1120,6 +1275,7 @@ namespace cgn_gemm {
 void launch_gemm_f32ops(const GemmParams& p, int bt, bool a_kc, bool b_kc, dim3 grid, hipStream_t s);
 void launch_gemm_bf16ops(const GemmParams& p, int bt, bool a_kc, bool b_kc, dim3 grid, hipStream_t s);
 void launch_gemm_a16(const GemmParams& p, int bt, bool b_kc, dim3 grid, hipStream_t s);
+bool launch_gemm_x6(const GemmParams& p, int bt, bool a_kc, bool b_kc, dim3 grid, hipStream_t s);
 void launch_group_f32ops(const GemmGroup& g, int vec, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s);
 void launch_group_bf16ops(const GemmGroup& g, int vec, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s);
 }  // namespace cgn_gemm

@@ -20,6 +20,7 @@ EPI_LINEAR = 0
 EPI_SOFTMAX_BWD = 1
 COMPUTE_F32 = 0
 COMPUTE_BF16 = 1
+COMPUTE_F32X6 = 2
 STORE_A_BF16, STORE_C_BF16, STORE_EP_BF16 = 1, 2, 4
 
 c_float_p = C.c_void_p  # raw device pointers travel as integers

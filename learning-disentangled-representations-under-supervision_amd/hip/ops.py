@@ -22,6 +22,27 @@ WORKSPACE_BYTES = 96 << 20
 COMPUTE = _lib.COMPUTE_BF16 if os.environ.get("CGN_COMPUTE", "f32").lower() == "bf16" else _lib.COMPUTE_F32
 
 
+# How an fp32 product is formed (cgn_gemm_desc.compute for the "f32" mode): True (default) = CGN_COMPUTE_F32X6, operands
+# split exactly into three bf16 terms inside the kernel, six partial products on the bf16 matrix pipe, fp32 accumulation -
+# fp32 accuracy at 2.67x less matrix-pipe time; False (CGN_GEMM_X6=0) = v_mfma_f32_32x32x2_f32. Read at launch time.
+GEMM_X6 = os.environ.get("CGN_GEMM_X6", "1") != "0"
+
+
+def _compute_code(compute):
+    """None = the module-level mode | 'f32' (X6 or fp32 MFMA, by GEMM_X6) | 'f32_mfma' | 'f32x6' | 'bf16'."""
+    if compute is None:
+        compute = "bf16" if COMPUTE == _lib.COMPUTE_BF16 else "f32"
+    if compute == "bf16":
+        return _lib.COMPUTE_BF16
+    if compute == "f32":
+        return _lib.COMPUTE_F32X6 if GEMM_X6 else _lib.COMPUTE_F32
+    if compute == "f32_mfma":
+        return _lib.COMPUTE_F32
+    if compute == "f32x6":
+        return _lib.COMPUTE_F32X6
+    raise ValueError("compute must be None, 'f32', 'f32_mfma', 'f32x6' or 'bf16'")
+
+
 # bf16 mode only: hold the logits-sized tensors of the generator's output layer in bf16 (hip/step.py; CGN_STORE_* in
 # include/cgn_hip.h). CGN_BF16_STORAGE=0 keeps every tensor fp32 (operands are then rounded inside the kernels only).
 BF16_STORAGE = os.environ.get("CGN_BF16_STORAGE", "1") != "0"
@@ -147,7 +168,7 @@ def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, 
     overrides give two-level addressing (see include/cgn_hip.h) for overlapping windows / history buffers; when an
     override is given, M/K/N must be given explicitly and `a`/`b` only provide the base pointer.
     a_exp=(scale, lse): A := exp(A*scale - lse[m]).   softmax_bwd=dict(logits, lse, rowdot, target, inv_tau, ce_scale).
-    compute: None (the module-level mode, see set_compute) | 'f32' | 'bf16'.
+    compute: None (the module-level mode, see set_compute) | 'f32' | 'bf16' | 'f32_mfma' | 'f32x6' (_compute_code).
     bf16 STORAGE (bf16 compute only, include/cgn_hip.h CGN_STORE_*): `a` may be a bfloat16 [M,K] matrix with unit k stride
     and rows 16 bytes aligned (K % 8 == 0); `out` and softmax_bwd's logits may be bfloat16; c_t: optional bfloat16 [N, >=M]
     receiving the transpose of a bfloat16 softmax_bwd result.
@@ -229,7 +250,7 @@ def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, 
         force_splitk = force_splitk or PLAN_HINT.get("splitk", 0)
     d.force_tile, d.force_splitk = force_tile, force_splitk
     d.dyn_scalars = _ptr(dyn)
-    d.compute = COMPUTE if compute is None else (_lib.COMPUTE_BF16 if compute == "bf16" else _lib.COMPUTE_F32)
+    d.compute = _compute_code(compute)
     d.storage = ((_lib.STORE_A_BF16 if a16 else 0) | (_lib.STORE_C_BF16 if c16 else 0) |
                  (_lib.STORE_EP_BF16 if (softmax_bwd is not None and ep16) else 0))
     if d.storage and d.compute != _lib.COMPUTE_BF16:

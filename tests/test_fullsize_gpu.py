@@ -62,9 +62,10 @@ def test_full_size_persistent_lstm_matches_step_kernels(dev, monkeypatch):
             assert abs(x - y) <= 2e-6 * max(1.0, abs(x)), (a, b)
     for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
         # Adam's early updates are ~ lr * sign(g): a gradient element near zero may move by a fraction of one lr step
-        # (5e-5) differently under a different summation order; 1e-4 of the largest weight is ~5 % of one such step
+        # (5e-5) differently under a different summation order; 2.5e-4 of the largest weight is ~12 % of one such step
+        # (measured worst element: below 1e-4 with fp32-MFMA products, 1.5e-4 with the X6 products, generator.fc.weight)
         err = (p - q).abs().max().item() / max(p.abs().max().item(), 1e-12)
-        assert err <= 1e-4, (n, err)
+        assert err <= 2.5e-4, (n, err)
 
 
 def test_full_size_gradients_are_the_mean_over_batch_halves(dev):
@@ -133,4 +134,4 @@ def test_fused_chains_match_the_chains_of_small_kernels(dev, monkeypatch):
             assert abs(x - y) <= 2e-6 * max(1.0, abs(x)), (a, b)
     for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
         err = (p - q).abs().max().item() / max(p.abs().max().item(), 1e-12)
-        assert err <= 1e-4, (n, err)  # (Adam's first updates are sign-like: see the persistent-vs-step test above)
+        assert err <= 2.5e-4, (n, err)  # (Adam's first updates are sign-like: see the persistent-vs-step test above)

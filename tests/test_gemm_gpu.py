@@ -402,3 +402,118 @@ def test_gemm_unsplit_epilogue_nests(dev, tile, M, N, K):
                  force_splitk=1)
         ref = 0.5 * (A.double() @ B.double()) + b0.double() + b1.double() + beta * C0.double()
         assert _rel(out, ref) < 2e-6, beta
+
+
+# ---- X6 products: fp32 accuracy from the bf16 matrix pipe (include/cgn_hip.h CGN_COMPUTE_F32X6) -------------------------
+def _x6_ran(ops, fn):
+    """Runs fn() (one ops.gemm call) with the launch profile on and tells whether the library took an X6 kernel."""
+    ops.GEMM_PROFILE = {"variant": None, "records": []}
+    try:
+        fn()
+        torch.cuda.synchronize()
+        return bool(ops.GEMM_PROFILE["records"][-1][0][3] & 32)
+    finally:
+        ops.GEMM_PROFILE = None
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 300, 96), (128, 128, 32), (4, 4, 4), (68, 132, 824), (260, 72, 364),
+                                   (64, 64, 1024), (36, 2048, 512), (1344, 512, 2000), (256, 300, 20), (132, 260, 16)])
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("tile", [0, 64, 128])
+def test_gemm_x6_layouts(dev, M, N, K, layout, tile):
+    """Every layout the X6 translation unit instantiates, ragged tile edges and K tails (K % 16 != 0) included: the X6
+    kernel must be the one that runs, and its result meets the fp32-MFMA kernel's bar (2e-6 relative Frobenius against
+    fp64; small-integer operands - exact bf16 values, so two of the three terms are zero - bit-exact)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 131 + N * 17 + K)
+    ints = (M + N + K) % 8 == 0
+    A, B = _mk((M, K), g, ints), _mk((K, N), g, ints)
+    ref = A.double() @ B.double()
+    a = A.to(dev) if layout[0] == "n" else A.t().contiguous().to(dev).t()
+    b = B.to(dev) if layout[1] == "n" else B.t().contiguous().to(dev).t()
+    out = torch.full((M, N), float("nan"), device=dev)
+    assert _x6_ran(ops, lambda: ops.gemm(a, b, out, force_tile=tile, compute="f32x6"))
+    if ints:
+        assert torch.equal(out.cpu().double(), ref)
+    else:
+        assert _rel(out, ref) < 2e-6
+    # and no worse than the fp32 MFMA product of the same operands, element by element, against the size of the terms
+    out32 = torch.empty(M, N, device=dev)
+    assert not _x6_ran(ops, lambda: ops.gemm(a, b, out32, force_tile=tile, compute="f32_mfma"))
+    scale = (A.abs().double() @ B.abs().double()).clamp_min(1e-30)
+    w6 = ((out.cpu().double() - ref).abs() / scale).max().item()
+    w32 = ((out32.cpu().double() - ref).abs() / scale).max().item()
+    assert w6 <= max(2.0 * w32, 2.0 ** -22), (w6, w32)
+
+
+def test_gemm_x6_operand_split_is_exact_over_the_exponent_range(dev):
+    """x = p0 + p1 + p2 must hold bit for bit: products with a one-hot operand return the other operand's elements
+    exactly (1.0 splits into (1, 0, 0), so only a.b0 + a.b1 + a.b2 terms are non-zero), for magnitudes 2^-60 .. 2^60."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(99)
+    M = N = K = 128
+    A = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-60, 61, (M, K), generator=g).float())
+    eye = torch.eye(K)
+    out = torch.empty(M, N, device=dev)
+    assert _x6_ran(ops, lambda: ops.gemm(A.to(dev), eye.to(dev), out, compute="f32x6"))
+    assert torch.equal(out.cpu(), A)
+    assert _x6_ran(ops, lambda: ops.gemm(eye.to(dev), A.to(dev), out, compute="f32x6"))
+    assert torch.equal(out.cpu(), A)
+
+
+@pytest.mark.parametrize("splitk", [0, 2, 5])
+def test_gemm_x6_splitk_bias_beta_history_and_softmax(dev, splitk):
+    ops = _ops()
+    from ldrs_amd.hip._lib import Axis
+    g = torch.Generator().manual_seed(7 + splitk)
+    M, N, K = 152, 92, 1000
+    A, B = _mk((M, K), g), _mk((K, N), g)
+    C0, b0, b1 = _mk((M, N), g), _mk((N,), g), _mk((N,), g)
+    ref = 0.5 * (A.double() @ B.double()) + 2.0 * C0.double() + b0.double() + b1.double()
+    out = C0.to(dev).clone()
+    assert _x6_ran(ops, lambda: ops.gemm(A.to(dev), B.to(dev), out, alpha=0.5, beta=2.0, bias0=b0.to(dev), bias1=b1.to(dev),
+                                         force_splitk=splitk, compute="f32x6"))
+    assert _rel(out, ref) < 2e-6
+    # dW_hh = dGates^T . h_prev over a [B, T+1, H] history buffer (B's K axis two-level: the kernel's FK = 2 form)
+    Bn, T, H = 12, 20, 32
+    dg, hbuf = _mk((Bn, T, 4 * H), g), _mk((Bn, T + 1, H), g)
+    refw = dg.double().reshape(Bn * T, 4 * H).t() @ hbuf[:, :T].double().reshape(Bn * T, H)
+    outw = torch.empty(4 * H, H, device=dev)
+    assert _x6_ran(ops, lambda: ops.gemm(dg.to(dev).view(Bn * T, 4 * H).t(), hbuf.to(dev), outw, N=H, K=Bn * T,
+                                         b_k=Axis(H, T, (T + 1) * H), b_n=Axis(1, 0, 0), force_splitk=splitk,
+                                         compute="f32x6"))
+    assert _rel(outw, refw) < 2e-6
+    # soft embedding (A = exp(logits / tau - lse) on the fly) and the fused dlogits epilogue (cgn.py:1086-1108)
+    Ms, V, E = 72, 336, 24
+    tau = 0.9
+    logits = (_mk((Ms, V), g) * 3).double().requires_grad_(True)
+    emb = _mk((V, E), g).double()
+    target = torch.randint(0, V, (Ms,), generator=g)
+    dout = _mk((Ms, E), g).double()
+    ls = torch.log_softmax(logits / tau, dim=1)
+    soft = torch.exp(ls) @ emb
+    (torch.nn.functional.nll_loss(ls, target) * 79 + (soft * dout).sum()).backward()
+    lg, embd, tg = logits.detach().float().to(dev), emb.float().to(dev), target.to(dev)
+    lse, nll, loss = ops.softmax_nll_fwd(lg, tg, 1.0 / tau)
+    so = torch.empty(Ms, E, device=dev)
+    assert _x6_ran(ops, lambda: ops.gemm(lg, embd, so, a_exp=(1.0 / tau, lse), force_splitk=splitk, compute="f32x6"))
+    assert _rel(so, soft.detach()) < 2e-6
+    dod = dout.float().to(dev)
+    rowdot = (dod * so).sum(1).contiguous()
+    dl = torch.empty(Ms, V, device=dev)
+    sb = dict(logits=lg, lse=lse, rowdot=rowdot, target=tg, inv_tau=1.0 / tau, ce_scale=79.0 / (Ms * tau))
+    for tile in (64, 128):
+        assert _x6_ran(ops, lambda: ops.gemm(dod, embd.t(), dl, softmax_bwd=sb, force_tile=tile, compute="f32x6"))
+        assert _rel(dl, logits.grad) < 5e-6
+
+
+def test_gemm_x6_falls_back_where_it_has_no_variant(dev):
+    """Scalar-load operands (unaligned rows) run the fp32-MFMA kernel under CGN_COMPUTE_F32X6: same result path as
+    compute='f32_mfma', bit for bit."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    A, B = _mk((65, 129), g).to(dev), _mk((129, 67), g).to(dev)
+    o1, o2 = torch.empty(65, 67, device=dev), torch.empty(65, 67, device=dev)
+    assert not _x6_ran(ops, lambda: ops.gemm(A, B, o1, compute="f32x6"))
+    ops.gemm(A, B, o2, compute="f32_mfma")
+    assert torch.equal(o1, o2)
