@@ -35,9 +35,13 @@ int g_order = 2;   // tile-order experiment knob (cgn_debug_set_stages bits 4..7
 // Tile / split-K heuristic: MI355X has 256 CUs and this kernel fits ~3-4 blocks per CU; aim for >= ~512 blocks.
 // x6: the product will run an X6 kernel (run_gemm / cgn_gemm_plan know after prepare_gemm)
 int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out, bool x6 = false) {
-    static const int x6_tile = getenv("CGN_X6_TILE") ? atoi(getenv("CGN_X6_TILE")) : 0;       // experiment knobs
-    static const int x6_blocks = getenv("CGN_X6_BLOCKS") ? atoi(getenv("CGN_X6_BLOCKS")) : 1024;
-    static const int x6_mink = getenv("CGN_X6_MINK") ? atoi(getenv("CGN_X6_MINK")) : 512;
+    // X6 products take the 128-tile from 256 x 256 outputs on: its 64-tile kernel stages three planes per operand for a
+    // quarter of the MFMAs and is bound by its LDS writes (same-box A/B, cfg2 step: 2.63 -> 2.52 ms with the mid-size
+    // products - 160-280 tiles of K 825-2484 - on the 128-tile; cfg4 shapes 45.1 -> 43.9 ms). CGN_X6_TILE=64 restores
+    // the fp32 kernels' tile choice for A/B runs. Splitting these products further along K (>= 256 or 128 per split
+    // instead of 512) made them 4-8 % faster alone and the step 3-9 % slower: slab traffic and reduce launches beside
+    // the other streams' work (profiles/r03_x6_tiles.txt).
+    static const int x6_tile = getenv("CGN_X6_TILE") ? atoi(getenv("CGN_X6_TILE")) : 128;
     // Measured on MI355X (tools/gemm_bench.py): the kernel needs >= ~4 blocks per CU to keep the MFMA pipes fed, the
     // 128-tile is the better choice once there are enough of them, and tall-K products want K split across blocks.
     const long t128 = (long)cgn_cdiv(d->M, 128) * cgn_cdiv(d->N, 128);
@@ -88,9 +92,8 @@ int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out
         // handful of tiles (e2mu/e2logvar, d[z,c], the text-CNN windows) are pure latency chains of K/BK dependent
         // steps on one CU each: split them hard, whatever their FLOP count.
         const bool few = tiles < 64;
-        const int min_k = few ? 128 : (bt == 128 ? ((x6 && x6_tile == 128) ? x6_mink : 512) : 256);
+        const int min_k = few ? 128 : (bt == 128 ? 512 : 256);
         long want = tiles >= 512 ? 1 : (1024 + tiles - 1) / tiles;
-        if (x6 && bt == 128 && x6_tile == 128) want = tiles >= 384 ? 1 : (x6_blocks + tiles / 2) / tiles;
         // tall-K on the 64-tile (the soft embedding, 105 tiles x K = 20000): ~5 blocks per CU measured better than 4
         // (inside the step: split 12 or 16 -> 2.98 ms, split 10 -> 3.00 ms)
         if (bt == 64 && d->K >= 4096 && tiles < 512) want = (1280 + tiles - 1) / tiles;
