@@ -108,9 +108,10 @@ def gemm_symbol(sym):
     b = lambda v: "true" if v else "false"  # noqa: E731
     # vec: bits 0/1 = 16-byte loads on A/B (the template's VEC), bits 2.. = fast K addressing mode (the template's FK)
     # bit 4 = A stored as bf16 (the template's A16), bit 5 = the X6 kernel ran (three-term bf16 split of fp32 operands)
-    if is_x6(sym):
-        return "cgn_gemm::gemm_kernel<%d, %s, %s, %d, %s, 2, %d, %s, true, %d, false, true>" % (
-            bt, b(a_kc), b(b_kc), vec & 3, b(exp), 16 if bt == 128 else 32, b(smb), (vec >> 2) & 3)
+    if is_x6(sym):  # (bit 6: the variant whose epilogue also leaves the log-softmax statistics, the template's LSE)
+        return "cgn_gemm::gemm_kernel<%d, %s, %s, %d, %s, 2, %d, %s, true, %d, false, true%s>" % (
+            bt, b(a_kc), b(b_kc), vec & 3, b(exp), 16 if bt == 128 else 32, b(smb), (vec >> 2) & 3,
+            ", true" if vec & 64 else "")
     kstep = (16 if bt == 128 else 32) * (2 if bf16 else 1)
     return "cgn_gemm::gemm_kernel<%d, %s, %s, %d, %s, 2, %d, %s, %s, %d, %s>" % (
         bt, b(a_kc), b(b_kc), vec & 3, b(exp), kstep, b(smb), b(bf16), (vec >> 2) & 3, b(vec & 16))

@@ -65,6 +65,15 @@ typedef struct cgn_axis {
 
 #define CGN_EPI_LINEAR 0      /* C = alpha*acc + beta*C + bias0[n] + bias1[n] */
 #define CGN_EPI_SOFTMAX_BWD 1 /* see cgn_gemm_desc.ep_* */
+/* CGN_EPI_LINEAR with beta == 0 PLUS the statistics a temperature softmax over the rows of C needs: the vocabulary
+ * projection fused with the first pass of the log-softmax / CE behind it (model/generator.py:61 ->
+ * model/cgn.py:1086-1092), so that the [B*T, V] logits are not read back for it. For row m and 64-column chunk c
+ * (columns [64c, 64c+64) below N), with s = ep_inv_tau (or dyn_scalars[0]):
+ *   ep_stats[(m * ep_stats_ld + c) * 2 + 0] = max_n s*C[m,n],  [... + 1] = sum_n exp(s*C[m,n] - that max).
+ * cgn_softmax_nll_from_stats_f32 combines the chunks into lse / NLL / mean NLL. Only products that run the 128-tile X6
+ * kernel unsplit can do this (both operands k-contiguous with 16-byte loads, compute == CGN_COMPUTE_F32X6, M, N >= 256):
+ * ask cgn_gemm_stats_chunks first; cgn_gemm_f32 returns CGN_ERR_INVALID_ARG for a descriptor it cannot serve. */
+#define CGN_EPI_LINEAR_STATS 2
 
 typedef struct cgn_gemm_desc {
     const float* A;
@@ -113,9 +122,15 @@ typedef struct cgn_gemm_desc {
      * k-contiguous A operand of the weight-gradient product dW_fc = dlogitsᵀ · h (model/generator.py:22,61 backward). */
     void* c_t;
     int64_t ld_ct;
+    /* CGN_EPI_LINEAR_STATS only: [M][ep_stats_ld][2] floats out, ep_stats_ld >= ceil(N / 64) */
+    float* ep_stats;
+    int64_t ep_stats_ld;
 } cgn_gemm_desc;
 
 int cgn_gemm_f32(void* stream, const cgn_gemm_desc* desc /* host */);
+/* *chunks = ceil(N / 64) when cgn_gemm_f32 would serve this descriptor with epilogue CGN_EPI_LINEAR_STATS (the
+ * descriptor's epilogue field may still say CGN_EPI_LINEAR; ep_stats is not looked at), 0 when it would not. */
+int cgn_gemm_stats_chunks(const cgn_gemm_desc* desc /* host */, int32_t* chunks /* host, out */);
 /* n <= 8 independent products in ONE launch (64x64 tiles, linear epilogue, no A transform; all members must have the
  * same operand orientations and compute type). For the chains of small same-shaped convolution products: the six
  * char-TDNN widths (selfModules/tdnn.py:41-44, a Python loop over F.conv1d) and the text-CNN's filter widths
@@ -150,6 +165,16 @@ int cgn_softmax_nll_fwd_f32(void* stream, const float* logits, int64_t ld, const
 int cgn_softmax_nll_fwd_bf16(void* stream, const void* logits, int64_t ld, const int64_t* target, int32_t M, int32_t V,
                              float inv_tau, const float* dyn_inv_tau /* device, nullable: overrides inv_tau */,
                              float* lse, float* nll, float* loss);
+
+/* The second half of the fused vocabulary projection + log-softmax + CE (model/generator.py:61 -> model/cgn.py:1086-1092):
+ * combines the per-chunk statistics a CGN_EPI_LINEAR_STATS product left in stats [M][ld_stats][2] (chunks per row =
+ * ceil(V / 64)) into lse / nll / loss exactly as cgn_softmax_nll_fwd_f32 defines them; of the logits only the M target
+ * elements are read. inv_tau (dyn_inv_tau) must be the product's ep_inv_tau. scratch: (ceil(M / 4) + 1) 4-byte words,
+ * the first zero on entry and left zero (the ticket of the fixed-order mean). */
+int cgn_softmax_nll_from_stats_f32(void* stream, const float* stats, int64_t ld_stats, int32_t chunks,
+                                   const float* logits, int64_t ld, const int64_t* target, int32_t M, int32_t V,
+                                   float inv_tau, const float* dyn_inv_tau /* device, nullable */, float* lse, float* nll,
+                                   float* loss, void* scratch /* device */, int64_t scratch_bytes);
 
 /* The sampler's learning=True output (model/cgn.py:880,901-902 with utils/beam_search.py:140-152 get_hyp_probs): the
  * log_softmax rows (cgn.py:803) of the parent beams on the best hypothesis' back-pointer chain, picked after the search:

@@ -2,4 +2,4 @@
 //   5: persistent LSTM scratch is zeroed once by the caller (no per-launch memset, no per-launch timeout word)
 #include "common.h"
 
-extern "C" int cgn_abi_version(void) { return 5; }
+extern "C" int cgn_abi_version(void) { return 6; }

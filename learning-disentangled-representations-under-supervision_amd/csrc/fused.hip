@@ -480,6 +480,60 @@ __global__ __launch_bounds__(64 * C2R_MAX_WAVES) void col2im_rowdot_kernel(const
     }
 }
 
+// ---- log-softmax / CE from the vocabulary projection's per-chunk statistics ------------------------------------------
+// (model/cgn.py:1086-1092 behind generator.py:61; the product's CGN_EPI_LINEAR_STATS epilogue left, per row and 64-column
+// chunk, the maximum of logits/tau and the exp-sum around it.) One wave per row: lse = M + log(sum_c s_c e^{m_c - M}),
+// nll = lse - logits[row, target]/tau - the only logits read here; mean NLL in fixed order by the last workgroup.
+constexpr int LS_NT = 256;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(LS_NT) void softmax_nll_from_stats_kernel(const float* __restrict__ stats, long ld_stats,
+                                                                       int chunks, const float* __restrict__ logits,
+                                                                       long ld, const long* __restrict__ target, int M,
+                                                                       float inv_tau, const float* __restrict__ dyn,
+                                                                       float* __restrict__ lse, float* __restrict__ nll,
+                                                                       float* __restrict__ loss, float* rows,
+                                                                       unsigned* ticket) {
+    __shared__ float part[LS_NT / 64];
+    __shared__ int s_flag;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (LS_NT / 64) + wave;
+    const float sc = dyn ? dyn[0] : inv_tau;
+    float v = 0.f;
+    if (row < M) {
+        const f32x2* st = reinterpret_cast<const f32x2*>(stats + (long)row * ld_stats * 2);
+        float m = -INFINITY;
+        for (int c = lane; c < chunks; c += 64) m = fmaxf(m, st[c][0]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int c = lane; c < chunks; c += 64) {
+            const f32x2 q = st[c];
+            s += q[1] * __expf(q[0] - m);
+        }
+        s = wave_sum(s);
+        const float l = m + logf(s);
+        if (lane == 0) {
+            const float n = l - logits[(long)row * ld + target[row]] * sc;
+            lse[row] = l;
+            nll[row] = n;
+            v = n;
+        }
+    }
+    if (lane == 0) part[wave] = v;
+    __syncthreads();
+    float bsum = 0.f;
+#pragma unroll
+    for (int w = 0; w < LS_NT / 64; ++w) bsum += part[w];
+    if (publish_and_check_last(rows, ticket, blockIdx.x, bsum, gridDim.x, &s_flag)) {
+        if (wave == 0) {
+            const float s = ordered_sum_wave0(rows, gridDim.x);
+            if (lane == 0) {
+                loss[0] = s / (float)M;
+                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 #define S_(x) ((hipStream_t)(x))
@@ -565,6 +619,22 @@ extern "C" int cgn_conv_col2im_rowdot_f32(void* stream, int32_t n, const float* 
     const int nt = 64 * (cgn_cdiv(E, 64) < C2R_MAX_WAVES ? cgn_cdiv(E, 64) : C2R_MAX_WAVES);
     hipLaunchKernelGGL(col2im_rowdot_kernel, dim3(B * T), dim3(nt), 0, S_(stream), g, B, L, T, E, beta, dx, other, (long)ldo,
                        rowdot);
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}
+
+extern "C" int cgn_softmax_nll_from_stats_f32(void* stream, const float* stats, int64_t ld_stats, int32_t chunks,
+                                              const float* logits, int64_t ld, const int64_t* target, int32_t M, int32_t V,
+                                              float inv_tau, const float* dyn_inv_tau, float* lse, float* nll, float* loss,
+                                              void* scratch, int64_t scratch_bytes) {
+    CGN_CHECK_ARG(M > 0 && V > 0 && chunks == cgn_cdiv(V, 64) && ld_stats >= chunks && ld >= V);
+    CGN_CHECK_ARG(stats && logits && target && lse && nll && loss && scratch && (uintptr_t)stats % 8 == 0);
+    const int blocks = cgn_cdiv(M, LS_NT / 64);
+    CGN_CHECK_ARG(scratch_bytes >= (int64_t)(blocks + 1) * 4);
+    unsigned* ticket = (unsigned*)scratch;
+    hipLaunchKernelGGL(softmax_nll_from_stats_kernel, dim3(blocks), dim3(LS_NT), 0, S_(stream), stats, (long)ld_stats, chunks,
+                       logits, (long)ld, (const long*)target, M, inv_tau, dyn_inv_tau, lse, nll, loss, (float*)(ticket + 1),
+                       ticket);
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }

@@ -167,7 +167,8 @@ static int prepare_gemm(const cgn_gemm_desc* d, GemmParams& p, bool& a_kc, bool&
     CGN_CHECK_ARG((d->a_m.rpg == 0 || d->M < (1 << 24)) && (d->b_n.rpg == 0 || d->N < (1 << 24)) &&
                   ((d->a_k.rpg == 0 && d->b_k.rpg == 0) || d->K < (1 << 24)));
     CGN_CHECK_ARG(d->a_transform == CGN_ATRANS_NONE || (d->a_transform == CGN_ATRANS_EXP && d->a_row_param));
-    CGN_CHECK_ARG(d->epilogue == CGN_EPI_LINEAR || d->epilogue == CGN_EPI_SOFTMAX_BWD);
+    CGN_CHECK_ARG(d->epilogue == CGN_EPI_LINEAR || d->epilogue == CGN_EPI_SOFTMAX_BWD ||
+                  d->epilogue == CGN_EPI_LINEAR_STATS);
     if (d->epilogue == CGN_EPI_SOFTMAX_BWD)
         CGN_CHECK_ARG(d->ep_logits && d->ep_lse && d->ep_rowdot && d->ep_target && d->ep_ld >= d->N);
     CGN_CHECK_ARG(d->force_tile == 0 || d->force_tile == 64 || d->force_tile == 128);
@@ -193,7 +194,9 @@ static int prepare_gemm(const cgn_gemm_desc* d, GemmParams& p, bool& a_kc, bool&
     p.ldc = d->ldc; p.ep_ld = d->ep_ld;
     p.am = make_axis(d->a_m); p.ak = make_axis(d->a_k); p.bk = make_axis(d->b_k); p.bn = make_axis(d->b_n);
     p.M = d->M; p.N = d->N; p.K = d->K;
-    p.a_transform = d->a_transform; p.epilogue = d->epilogue;
+    p.a_transform = d->a_transform;
+    p.epilogue = d->epilogue == CGN_EPI_LINEAR_STATS ? CGN_EPI_LINEAR : d->epilogue;  // (C itself is the linear epilogue's)
+    p.stats = nullptr; p.ldstats = 0;
     p.alpha = d->alpha; p.beta = d->beta; p.a_scale = d->a_scale;
     p.ep_inv_tau = d->ep_inv_tau; p.ep_ce_scale = d->ep_ce_scale;
     p.a16 = a16; p.c16 = c16; p.ep16 = ep16; p.ct = d->c_t; p.ldct = d->ld_ct;
@@ -248,6 +251,27 @@ static bool x6_variant_exists(const GemmParams& p, bool a_kc, bool b_kc) {
     return !(!a_kc && b_kc);
 }
 
+// CGN_EPI_LINEAR_STATS is served by one kernel: the unsplit 128-tile X6 product of two k-contiguous operands
+static bool stats_servable(const cgn_gemm_desc* d, const GemmParams& p, bool a_kc, bool b_kc) {
+    return d->compute == CGN_COMPUTE_F32X6 && x6_variant_exists(p, a_kc, b_kc) && p.fastk == 1 && a_kc && b_kc &&
+           d->a_transform == CGN_ATRANS_NONE && d->beta == 0.f && d->M >= 256 && d->N >= 256 &&
+           (d->force_tile == 0 || d->force_tile == 128) && d->force_splitk <= 1 && d->storage == 0;
+}
+
+extern "C" int cgn_gemm_stats_chunks(const cgn_gemm_desc* d, int32_t* chunks) {
+    CGN_CHECK_ARG(d && chunks);
+    *chunks = 0;
+    GemmParams p;
+    bool a_kc = false, b_kc = false;
+    cgn_gemm_desc lin = *d;
+    if (lin.epilogue == CGN_EPI_LINEAR_STATS) lin.epilogue = CGN_EPI_LINEAR;
+    if (lin.epilogue != CGN_EPI_LINEAR) return CGN_OK;
+    const int rc = prepare_gemm(&lin, p, a_kc, b_kc);
+    if (rc) return rc;
+    if (d->M > 0 && d->N > 0 && stats_servable(d, p, a_kc, b_kc)) *chunks = cgn_cdiv(d->N, 64);
+    return CGN_OK;
+}
+
 static int run_gemm(void* stream, const cgn_gemm_desc* d, hipEvent_t ev_start, hipEvent_t ev_stop,
                     int32_t* vec_mode = nullptr) {
     GemmParams p;
@@ -263,6 +287,15 @@ static int run_gemm(void* stream, const cgn_gemm_desc* d, hipEvent_t ev_start, h
         const int rc = plan_gemm(d, &bt, &splitk, &kps, x6);
         if (rc) return rc;
     }
+    if (d->epilogue == CGN_EPI_LINEAR_STATS) {
+        CGN_CHECK_ARG(stats_servable(d, p, a_kc, b_kc) && d->ep_stats && d->ep_stats_ld >= cgn_cdiv(d->N, 64) &&
+                      (uintptr_t)d->ep_stats % 8 == 0);
+        bt = 128;
+        splitk = 1;
+        kps = cgn_cdiv(d->K > 0 ? d->K : 1, KROUND) * KROUND;
+        p.stats = d->ep_stats;
+        p.ldstats = d->ep_stats_ld;
+    }
     if (p.c16 && splitk > 1) {  // a bf16 C is written by the product kernel itself: no slabs, no reduce pass
         splitk = 1;
         kps = cgn_cdiv(d->K > 0 ? d->K : 1, KROUND) * KROUND;
@@ -276,7 +309,8 @@ static int run_gemm(void* stream, const cgn_gemm_desc* d, hipEvent_t ev_start, h
 
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)tiles, (unsigned)splitk);
-    if (vec_mode) *vec_mode = (p.a_vec ? 1 : 0) | (p.b_vec ? 2 : 0) | (p.fastk << 2) | (p.a16 ? 16 : 0) | (x6 ? 32 : 0);
+    if (vec_mode) *vec_mode = (p.a_vec ? 1 : 0) | (p.b_vec ? 2 : 0) | (p.fastk << 2) | (p.a16 ? 16 : 0) | (x6 ? 32 : 0) |
+                              (p.stats ? 64 : 0);
     if (ev_start && hipEventRecord(ev_start, s) != hipSuccess) return CGN_ERR_HIP_BASE + (int)hipGetLastError();
     if (p.a16)
         launch_gemm_a16(p, bt, b_kc, grid, s);

@@ -83,6 +83,9 @@ struct GemmParams {
     int a16, c16, ep16;
     void* ct;
     long ldct;
+    // CGN_EPI_LINEAR_STATS (template flag LSE): per (row, 64-column chunk) softmax statistics of ep_inv_tau * C
+    float* stats;
+    long ldstats;
 };
 
 constexpr int g_unroll_mult = 2;
@@ -517,8 +520,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // SMB: the batched softmax-backward epilogue is compiled in (only the dlogits product's variant: inside the shared
 // variant its registers cost the vocabulary projection 10 %).
 template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK, bool SMB = false, bool BF = false,
-          int FK = 0, bool A16 = false, bool X6 = false>
+          int FK = 0, bool A16 = false, bool X6 = false, bool LSE = false>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, const int t) {
+    static_assert(!LSE || (X6 && BT == 128 && !SMB), "the statistics epilogue is built for the 128-tile X6 kernel");
     static_assert(!A16 || (BF && A_KC && (VEC & 1)), "bf16-stored A: bf16 MFMA operands, k-contiguous, 16-byte loads");
     static_assert(!X6 || (BF && !A16 && VEC == 3), "X6: fp32 operands in memory, three bf16 planes in LDS");
     constexpr int NP = X6 ? 3 : 1;   // planes per operand image
@@ -938,6 +942,53 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
         }
         return;
     }
+    if constexpr (LSE) {
+        // CGN_EPI_LINEAR_STATS (host: unsplit, beta == 0): the wave's 64x64 sub-tile of s * C goes through LDS (free after
+        // the K loop; rows 68 floats apart: a lane's 16-byte reads of its row are conflict-free), then lane l forms the
+        // maximum and the exp-sum of row l over the chunk's 64 columns in registers - no cross-lane reduction.
+        constexpr int RSF = 68;
+        static_assert(4 * 64 * RSF * 4 <= 4 * OPI * 4, "staging images must fit the operand buffers");
+        float* stage = lds + wave * (64 * RSF);
+        const float sc = p.dyn ? p.dyn[0] : p.ep_inv_tau;
+        __syncthreads();  // every wave is done with the operand images
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+            const int col = n0 + wn * (BT / 2) + j * 32 + fr;
+            const bool cok = col < p.N;
+            const int cc = cok ? col : 0;
+            const float b0 = p.bias0 ? p.bias0[cc] : 0.f, b1 = p.bias1 ? p.bias1[cc] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TW; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    const float v = (p.alpha * acc[0][i][j][r] + b0) + b1;  // (the linear nest's order: same C bits)
+                    stage[rl * RSF + j * 32 + fr] = cok ? v * sc : -INFINITY;
+                }
+        }
+        __syncthreads();
+        {
+            const float* rowp = stage + lane * RSF;
+            f32x4 x[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) x[q] = *reinterpret_cast<const f32x4*>(rowp + q * 4);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) mx = fmaxf(fmaxf(fmaxf(x[q][0], x[q][1]), fmaxf(x[q][2], x[q][3])), mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum += __expf(x[q][e] - mx);
+            const int row = m0 + wm * (BT / 2) + lane;
+            const int chunk = (n0 + wn * (BT / 2)) / 64;
+            if (row < p.M && chunk * 64 < p.N) {
+                f32x2 st = {mx, sum};
+                *reinterpret_cast<f32x2*>(p.stats + ((long)row * p.ldstats + chunk) * 2) = st;
+            }
+        }
+        // (C itself leaves through the linear nest below)
+    }
     // The common epilogues get LEAN loop nests of their own (one uniform branch picks the nest; per element: one bounds
     // test, one fma, one store off a per-column base pointer). The all-purpose apply_epilogue() inlined 64 times made
     // this part of the kernel ~60 KB of straight-line code: more than the instruction cache, run once per tile.
@@ -1018,7 +1069,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
 
 // (X6, 128-tile: BK = 16, 72 KB of LDS: two blocks per CU, whose waves cover each other's staging work)
 template <int BT, bool A_KC, bool B_KC, int VEC, bool EXP, int S, int BK = (BT == 128 ? 16 : 32), bool SMB = false,
-          bool BF = false, int FK = 0, bool A16 = false, bool X6 = false>
+          bool BF = false, int FK = 0, bool A16 = false, bool X6 = false, bool LSE = false>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
     // Work item = (K split, tile). Default (order 2): the XCD remap runs over the tile list, the shorter tile axis
     // fastest (gemm_tile: neighbouring tiles share a panel of the operand that spans the long axis). Orders 0/1 remap over the whole (split, tile) list so that an XCD
@@ -1036,7 +1087,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
         split = w / ntiles;
         t = w - split * ntiles;
     }
-    gemm_tile<BT, A_KC, B_KC, VEC, EXP, S, BK, SMB, BF, FK, A16, X6>(p, split, t);
+    gemm_tile<BT, A_KC, B_KC, VEC, EXP, S, BK, SMB, BF, FK, A16, X6, LSE>(p, split, t);
 }
 
 // Grouped launch: up to GROUP_MAX independent products (same kernel variant) in ONE launch; block b works on the
@@ -1217,6 +1268,11 @@ bool launch_x6_t(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream
     if constexpr (BT == 128) {
         if (a_kc && b_kc && p.epilogue == CGN_EPI_SOFTMAX_BWD && p.splitk == 1) {
             hipLaunchKernelGGL((gemm_kernel<BT, true, true, 3, false, 2, BK, true, true, 1, false, true>), grid, dim3(NT), 0, s, p);
+            return true;
+        }
+        if (p.stats) {  // CGN_EPI_LINEAR_STATS (run_gemm has checked: both operands k-contiguous, unsplit)
+            hipLaunchKernelGGL((gemm_kernel<BT, true, true, 3, false, 2, BK, false, true, 1, false, true, true>), grid, dim3(NT), 0,
+                               s, p);
             return true;
         }
     }

@@ -18,6 +18,7 @@ ATRANS_NONE = 0
 ATRANS_EXP = 1
 EPI_LINEAR = 0
 EPI_SOFTMAX_BWD = 1
+EPI_LINEAR_STATS = 2
 COMPUTE_F32 = 0
 COMPUTE_BF16 = 1
 COMPUTE_F32X6 = 2
@@ -50,6 +51,7 @@ class GemmDesc(C.Structure):
         ("dyn_scalars", c_ptr),
         ("compute", c_i32), ("storage", c_i32),
         ("c_t", c_ptr), ("ld_ct", c_i64),
+        ("ep_stats", c_ptr), ("ep_stats_ld", c_i64),
     ]
 
 
@@ -106,6 +108,9 @@ PROTOTYPES = {
                                           C.POINTER(c_i32), c_i32, c_i32, c_ptr, c_i64, c_ptr, c_i64]),
     "cgn_gemm_plan": (c_i32, [C.POINTER(GemmDesc), C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32),
                               C.POINTER(c_i32)]),
+    "cgn_gemm_stats_chunks": (c_i32, [C.POINTER(GemmDesc), C.POINTER(c_i32)]),
+    "cgn_softmax_nll_from_stats_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i32, c_i32, c_f32, c_ptr,
+                                               c_ptr, c_ptr, c_ptr, c_ptr, c_i64]),
     "cgn_softmax_nll_fwd_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_i32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "cgn_softmax_nll_fwd_bf16": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_i32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "cgn_log_softmax_rows_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i32, c_i64, c_i32, c_ptr, c_i64]),

@@ -161,7 +161,7 @@ PLAN_HINT = None
 
 def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, bias1=None,
          a_m=None, a_k=None, b_k=None, b_n=None, a_exp=None, softmax_bwd=None, force_tile=0, force_splitk=0,
-         dyn=None, compute=None, c_t=None, _desc_only=False):
+         dyn=None, compute=None, c_t=None, lse_stats=None, _desc_only=False):
     """out[M,N] = epilogue(alpha * A @ B + beta*out + bias0 + bias1).
 
     `a` is viewed as A[M,K] and `b` as B[K,N]; arbitrary 2-D strides (so `w.t()` is free). The optional cgn Axis
@@ -169,6 +169,9 @@ def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, 
     override is given, M/K/N must be given explicitly and `a`/`b` only provide the base pointer.
     a_exp=(scale, lse): A := exp(A*scale - lse[m]).   softmax_bwd=dict(logits, lse, rowdot, target, inv_tau, ce_scale).
     compute: None (the module-level mode, see set_compute) | 'f32' | 'bf16' | 'f32_mfma' | 'f32x6' (_compute_code).
+    lse_stats=inv_tau: ask for the fused log-softmax statistics of inv_tau * out (CGN_EPI_LINEAR_STATS: the vocabulary
+    projection with the first pass of the CE behind it); the call then returns (out, stats) with stats a [M, chunks, 2]
+    tensor for softmax_nll_from_stats(), or (out, None) where the library cannot serve this product that way.
     bf16 STORAGE (bf16 compute only, include/cgn_hip.h CGN_STORE_*): `a` may be a bfloat16 [M,K] matrix with unit k stride
     and rows 16 bytes aligned (K % 8 == 0); `out` and softmax_bwd's logits may be bfloat16; c_t: optional bfloat16 [N, >=M]
     receiving the transpose of a bfloat16 softmax_bwd result.
@@ -251,6 +254,15 @@ def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, 
     d.force_tile, d.force_splitk = force_tile, force_splitk
     d.dyn_scalars = _ptr(dyn)
     d.compute = _compute_code(compute)
+    stats = None
+    if lse_stats is not None and softmax_bwd is None and not (a16 or c16):
+        d.ep_inv_tau = float(lse_stats)
+        nch = C.c_int32()
+        _lib.check(lib.cgn_gemm_stats_chunks(C.byref(d), C.byref(nch)), "cgn_gemm_stats_chunks")
+        if nch.value > 0:
+            stats = alloc((M, nch.value, 2), dev)
+            d.epilogue = _lib.EPI_LINEAR_STATS
+            d.ep_stats, d.ep_stats_ld = _ptr(stats), nch.value
     d.storage = ((_lib.STORE_A_BF16 if a16 else 0) | (_lib.STORE_C_BF16 if c16 else 0) |
                  (_lib.STORE_EP_BF16 if (softmax_bwd is not None and ep16) else 0))
     if d.storage and d.compute != _lib.COMPUTE_BF16:
@@ -285,10 +297,10 @@ def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, 
             sym = key + (vec.value, d.a_transform == _lib.ATRANS_EXP, softmax_bwd is not None,
                          d.compute == _lib.COMPUTE_BF16)
             prof["records"].append((sym, s_.value, M, N, K, e0, e1))
-            return out
+            return out if lse_stats is None else (out, stats)
     with torch.cuda.device(dev):
         _lib.check(lib.cgn_gemm_f32(_stream(), C.byref(d)), "cgn_gemm_f32")
-    return out
+    return out if lse_stats is None else (out, stats)
 
 
 def gemm_group(calls):
@@ -355,6 +367,27 @@ def softmax_nll_fwd(logits, target, inv_tau, dyn=None):
     with torch.cuda.device(logits.device):
         _lib.check(getattr(lib, name)(_stream(), _ptr(logits), logits.stride(0), _ptr(target), M, V,
                                       inv_tau, _ptr(dyn), _ptr(lse), _ptr(nll), _ptr(loss)), name)
+    return lse, nll, loss
+
+
+# The vocabulary projection leaves the softmax statistics of its own output (gemm(lse_stats=...)): CGN_FUSED_LSE=0 keeps
+# the separate one-read softmax / NLL kernel (A/B switch; the bf16 mode and the fp32-MFMA products always use it)
+FUSED_LSE = os.environ.get("CGN_FUSED_LSE", "1") != "0"
+
+
+def softmax_nll_from_stats(stats, logits, target, inv_tau, dyn=None):
+    """(lse[M], nll[M], loss[1]) as softmax_nll_fwd defines them, from the statistics a gemm(lse_stats=inv_tau) product
+    left (cgn_softmax_nll_from_stats_f32): the logits are only read at the M target positions."""
+    _chk_f32(stats, "stats"), _chk_f32(logits, "logits"), _chk_i64(target, "target")
+    M, V = logits.shape
+    _req(stats.is_contiguous() and stats.dim() == 3 and stats.shape[0] == M and stats.shape[2] == 2
+         and stats.shape[1] == (V + 63) // 64 and logits.stride(1) == 1 and target.numel() == M
+         and (M + 3) // 4 + 1 <= FUSED_SCRATCH_WORDS, "softmax_nll_from_stats shapes")
+    lse, nll, loss = alloc((M,), logits.device), alloc((M,), logits.device), alloc((1,), logits.device)
+    ws = _fused_scratch_ws(logits.device)
+    _call("cgn_softmax_nll_from_stats_f32", logits.device, _ptr(stats), stats.shape[1], stats.shape[1], _ptr(logits),
+          logits.stride(0), _ptr(target), M, V, float(inv_tau), _ptr(dyn), _ptr(lse), _ptr(nll), _ptr(loss), _ptr(ws),
+          ws.numel() * 4)
     return lse, nll, loss
 
 

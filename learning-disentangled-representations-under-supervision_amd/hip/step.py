@@ -635,11 +635,22 @@ class CGNStep:
         store16 = (ops.get_compute() == "bf16" and ops.BF16_STORAGE and V % 8 == 0 and NT % 8 == 0 and E % 4 == 0
                    and Hg % 4 == 0 and table.stride(0) % 4 == 0)
         logits = _new((NT, V), dev, torch.bfloat16 if store16 else torch.float32)
-        ops.gemm(h1, P["generator.fc.weight"].t(), logits, M=NT, K=Hg, a_m=h1ax, a_k=LIN, bias0=P["generator.fc.bias"])
+        # fused vocabulary projection + log-softmax + CE (generator.py:61 -> cgn.py:1086-1092): where the product runs the
+        # X6 128-tile kernel its epilogue also leaves each row's per-chunk (max, exp-sum) of logits/tau, and a small kernel
+        # combines them and reads the M target logits - the 107.5 MB of logits are not read back for the CE
+        stats = None
+        if ops.FUSED_LSE and not store16:
+            _, stats = ops.gemm(h1, P["generator.fc.weight"].t(), logits, M=NT, K=Hg, a_m=h1ax, a_k=LIN,
+                                bias0=P["generator.fc.bias"], lse_stats=inv_tau, dyn=self._dyn())
+        else:
+            ops.gemm(h1, P["generator.fc.weight"].t(), logits, M=NT, K=Hg, a_m=h1ax, a_k=LIN, bias0=P["generator.fc.bias"])
         # ---- temperature softmax + CE (cgn.py:1086-1092) -------------------------------------------------------
         tgt = target.reshape(-1)
         ops.stamp("M vocabulary projection done")
-        lse, nll, ce = ops.softmax_nll_fwd(logits, tgt, inv_tau, dyn=self._dyn())
+        if stats is not None:
+            lse, nll, ce = ops.softmax_nll_from_stats(stats, logits, tgt, inv_tau, dyn=self._dyn())
+        else:
+            lse, nll, ce = ops.softmax_nll_fwd(logits, tgt, inv_tau, dyn=self._dyn())
         ops.stamp("M softmax/CE done")
         need_soft = use_disc or calc_z_loss
         # (a loss that this step does not compute reads as the engine's constant zero: no fill kernel on the critical path)

@@ -111,6 +111,33 @@ def test_full_size_uniform_logits_cross_entropy_is_log_vocab(dev):
     assert abs(float(ce) - math.log(ocfg.word_vocab_size)) < 1e-4
 
 
+@pytest.mark.parametrize("switch", ["FUSED_LSE", "GEMM_X6"])
+def test_step_switches_leave_the_training_unchanged(dev, monkeypatch, switch):
+    """Two full training steps at BASELINE configs[1] with and without (a) the log-softmax statistics fused into the
+    vocabulary projection (ops.FUSED_LSE: same logits, lse / NLL from per-chunk statistics instead of a second pass) and
+    (b) the X6 products (ops.GEMM_X6: fp32-accurate products on the bf16 pipe instead of fp32 MFMAs): same losses to
+    2e-6, same weights up to Adam's sign-like first updates."""
+    from ldrs_amd.hip import ops
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(ops, switch, on)
+        model, eng, opts, ocfg = _build(dev)
+        data, _ = bench.device_data(O, ocfg, bench.BATCH, bench.SEQ, 99, dev)
+        losses = []
+        for i in range(2):
+            dl, c, eg = eng.wake_sleep(opts, data, 0.9, 0.8, calc_z_loss=(i == 1))
+            losses.append([float(x) for x in dl] + [float(x) for x in eg[:4]] + [float(c.sum())])
+        torch.cuda.synchronize()
+        res.append((model, losses))
+    (m1, l1), (m2, l2) = res
+    for a, b in zip(l1, l2):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 2e-6 * max(1.0, abs(x)), (a, b)
+    for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        err = (p - q).abs().max().item() / max(p.abs().max().item(), 1e-12)
+        assert err <= 2.5e-4, (n, err)
+
+
 def test_fused_chains_match_the_chains_of_small_kernels(dev, monkeypatch):
     """csrc/fused.hip (code head forward / backward, c-reconstruction head, col2im + row dot product: one launch each)
     against the chains of small kernels they replace (ops.FUSED_CHAINS = False), two full training steps at BASELINE

@@ -517,3 +517,55 @@ def test_gemm_x6_falls_back_where_it_has_no_variant(dev):
     assert not _x6_ran(ops, lambda: ops.gemm(A, B, o1, compute="f32x6"))
     ops.gemm(A, B, o2, compute="f32_mfma")
     assert torch.equal(o1, o2)
+
+
+@pytest.mark.parametrize("M,V,K", [(1344, 20000, 512), (256, 300, 64), (320, 1000, 96), (260, 257, 32)])
+def test_gemm_fused_log_softmax_statistics(dev, M, V, K):
+    """The vocabulary projection with the CE's first pass in its epilogue (CGN_EPI_LINEAR_STATS, generator.py:61 ->
+    cgn.py:1086-1092): logits bit-identical to the plain product's, lse / nll / mean NLL against fp64 log_softmax of
+    those logits (2e-6) and against the stand-alone softmax kernel; ragged last chunks and row tiles included."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + V + K)
+    tau = 0.7
+    h, W, bias = _mk((M, K), g), _mk((V, K), g) * 0.3, _mk((V,), g)
+    tgt = torch.randint(0, V, (M,), generator=g)
+    hd, Wd, bd, td = h.to(dev), W.to(dev), bias.to(dev), tgt.to(dev)
+    plain = torch.empty(M, V, device=dev)
+    ops.gemm(hd, Wd.t(), plain, bias0=bd, compute="f32x6", force_tile=128)
+    logits = torch.full((M, V), float("nan"), device=dev)
+    out, stats = ops.gemm(hd, Wd.t(), logits, bias0=bd, compute="f32x6", lse_stats=1.0 / tau)
+    assert stats is not None and stats.shape == (M, (V + 63) // 64, 2)
+    assert torch.equal(logits, plain)
+    lse, nll, loss = ops.softmax_nll_from_stats(stats, logits, td, 1.0 / tau)
+    ls = torch.log_softmax(logits.double().cpu() / tau, dim=1)
+    ref_lse = torch.logsumexp(logits.double().cpu() / tau, dim=1)
+    ref_nll = -ls[torch.arange(M), tgt]
+    assert _rel(lse, ref_lse) < 2e-6 and _rel(nll, ref_nll) < 2e-6
+    assert abs(loss.item() - ref_nll.mean().item()) < 2e-6 * abs(ref_nll.mean().item())
+    lse2, nll2, loss2 = ops.softmax_nll_fwd(logits, td, 1.0 / tau)
+    assert _rel(lse, lse2.double().cpu()) < 1e-6 and abs(loss.item() - loss2.item()) < 2e-6 * abs(loss2.item())
+    # twice in a row (the ticket re-arms), with the temperature read from device memory the second time
+    dyn = torch.tensor([1.0 / tau, 0.0], device=dev)
+    logits.fill_(float("nan"))
+    _, stats_b = ops.gemm(hd, Wd.t(), logits, bias0=bd, compute="f32x6", lse_stats=123.0, dyn=dyn)
+    lse3, nll3, loss3 = ops.softmax_nll_from_stats(stats_b, logits, td, 123.0, dyn=dyn)
+    assert torch.equal(lse3, lse) and torch.equal(nll3, nll) and torch.equal(loss3, loss)
+
+
+def test_gemm_fused_statistics_are_refused_where_no_kernel_serves_them(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    a, b = _mk((300, 64), g).to(dev), _mk((64, 300), g).to(dev)  # B row-contiguous: not the NT product
+    out = torch.empty(300, 300, device=dev)
+    _, stats = ops.gemm(a, b, out, compute="f32x6", lse_stats=1.0)
+    assert stats is None
+    _, stats = ops.gemm(a, b.t().contiguous().t(), out, compute="f32_mfma", lse_stats=1.0)
+    assert stats is None
+    assert _rel(out, a.double().cpu() @ b.double().cpu()) < 2e-6
+    from ldrs_amd.hip import _lib
+    import ctypes as C
+    d = ops.gemm(a, b, out, compute="f32x6", _desc_only=True)
+    d.epilogue = _lib.EPI_LINEAR_STATS
+    d.ep_stats, d.ep_stats_ld = out.data_ptr(), 5
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        _lib.check(_lib.load().cgn_gemm_f32(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(d)), "cgn_gemm_f32")
