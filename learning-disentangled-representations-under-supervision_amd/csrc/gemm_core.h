@@ -950,7 +950,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
         static_assert(4 * 64 * RSF * 4 <= 4 * OPI * 4, "staging images must fit the operand buffers");
         float* stage = lds + wave * (64 * RSF);
         const float sc = p.dyn ? p.dyn[0] : p.ep_inv_tau;
-        __syncthreads();  // every wave is done with the operand images
+        // No workgroup barrier: behind the K loop's last barrier the waves only read the operand images (fragments of a
+        // tile past the end, which no MFMA consumes), and a wave's staging area is read by that wave alone.
 #pragma unroll
         for (int j = 0; j < TW; ++j) {
             const int col = n0 + wn * (BT / 2) + j * 32 + fr;
@@ -966,7 +967,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
                     stage[rl * RSF + j * 32 + fr] = cok ? v * sc : -INFINITY;
                 }
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes have landed (in-order LDS queue)
         {
             const float* rowp = stage + lane * RSF;
             f32x4 x[16];
