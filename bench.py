@@ -109,11 +109,10 @@ def gemm_symbol(sym):
     # vec: bits 0/1 = 16-byte loads on A/B (the template's VEC), bits 2.. = fast K addressing mode (the template's FK)
     # bit 4 = A stored as bf16 (the template's A16), bit 5 = the X6 kernel ran (three-term bf16 split of fp32 operands)
     if is_x6(sym):  # (bit 6: the variant whose epilogue also leaves the log-softmax statistics, the template's LSE)
-        return "cgn_gemm::gemm_kernel<%d, %s, %s, %d, %s, 2, %d, %s, true, %d, false, true%s>" % (
-            bt, b(a_kc), b(b_kc), vec & 3, b(exp), 16 if bt == 128 else 32, b(smb), (vec >> 2) & 3,
-            ", true" if vec & 64 else "")
+        return "cgn_gemm::gemm_kernel<%d, %s, %s, %d, %s, 2, %d, %s, true, %d, false, true, %s>" % (
+            bt, b(a_kc), b(b_kc), vec & 3, b(exp), 16 if bt == 128 else 32, b(smb), (vec >> 2) & 3, b(vec & 64))
     kstep = (16 if bt == 128 else 32) * (2 if bf16 else 1)
-    return "cgn_gemm::gemm_kernel<%d, %s, %s, %d, %s, 2, %d, %s, %s, %d, %s>" % (
+    return "cgn_gemm::gemm_kernel<%d, %s, %s, %d, %s, 2, %d, %s, %s, %d, %s, false, false>" % (
         bt, b(a_kc), b(b_kc), vec & 3, b(exp), kstep, b(smb), b(bf16), (vec >> 2) & 3, b(vec & 16))
 
 
@@ -338,7 +337,7 @@ def main():
         with open(path, "w") as f:
             f.write("# per-shape table of the step's GEMM products (%s, %s): HIP events directly around each MFMA kernel\n"
                     "# launch (split-K reduce launches excluded), %d instrumented steps; step time %.3f ms\n"
-                    "# frac = TFLOP/s over the kernel's MFMA roof: fp32 MFMA 157.3, X6 kernels (<..., true, FK, false, true>) bf16 peak / 6 = 416.7\n"
+                    "# frac = TFLOP/s over the kernel's MFMA roof: fp32 MFMA 157.3, X6 kernels (<..., true, FK, false, true, LSE>) bf16 peak / 6 = 416.7\n"
                     "# model = steady-state rate (0.92 | 0.86 of peak at 4096^3) x balance (tiles/CU over its ceiling, %d CUs)\n"
                     "#         x pad (M*N over the tile grid's area) x kshare (K steps per tile / (K steps + 8 | 4 of fixed cost))\n" %
                     (args.workload, args.compute, passes, ms_step, cus))

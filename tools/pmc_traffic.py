@@ -16,7 +16,7 @@ def load(d):
     agg = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
         n = re.sub(r"\(anonymous namespace\)::|cgn_gemm::", "", r["Kernel_Name"]).split("(")[0].replace("void ", "")
-        key = "%s g%d" % (n[:72], int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1))
+        key = "%s g%d" % (n[:110], int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1))
         agg.setdefault(key, []).append(float(r["Counter_Value"]) * 1024.0)
     return agg
 

@@ -5,7 +5,7 @@ import sqlite3
 import sys
 
 db, which = sys.argv[1], int(sys.argv[2])
-anchor = sys.argv[3] if len(sys.argv) > 3 else "softmax_nll_fwd"
+anchor = sys.argv[3] if len(sys.argv) > 3 else "softmax_nll_f"  # (softmax_nll_fwd_kernel | softmax_nll_from_stats_kernel)
 c = sqlite3.connect(db)
 cols = [d[1] for d in c.execute("pragma table_info(kernels)").fetchall()] or \
        [d[0] for d in c.execute("select * from kernels limit 0").description]
@@ -33,7 +33,7 @@ end_max = 0
 busy = 0
 print("step %d: %d kernels, span %.1f us" % (which, len(seg), (max(r[2] for r in seg) - t0) / 1e3))
 for i, (name, s, e, gx, wx, q) in enumerate(seg):
-    short = re.sub(r"\(anonymous namespace\)::", "", name).split("(")[0].replace("void ", "")[:40]
+    short = re.sub(r"\(anonymous namespace\)::", "", name).split("(")[0].replace("void ", "")[:64]
     ov = sum(1 for r in seg if r[1] < e and r[2] > s) - 1
     gap = (s - end_max) / 1e3 if end_max else 0.0
     print("%8.1f %7.1f us  q%d ov %d  gap %5.1f  g%-5d %s" % ((s - t0) / 1e3, (e - s) / 1e3, qids[q], ov, max(gap, 0.0),
