@@ -345,6 +345,9 @@ extern "C" int cgn_gemm_group_f32(void* stream, const cgn_gemm_desc* descs, int3
     GemmGroup g;
     g.n = 0;
     bool a_kc0 = false, b_kc0 = false, va = true, vb = true, bf16 = false;
+    // X6 group (128-tile): every member an X6 product of the same orientation and fast-K mode with >= 256 x 256 outputs
+    bool x6g = true, big_x6 = false;
+    int fk0 = -1;
     long tiles_total = 0, ws_floats = 0;
     float* ws = nullptr;
     for (int i = 0; i < n; ++i) {
@@ -365,7 +368,11 @@ extern "C" int cgn_gemm_group_f32(void* stream, const cgn_gemm_desc* descs, int3
         }
         va = va && p.a_vec && a_kc == a_kc0;  // 16-byte loads only if every member allows them
         vb = vb && p.b_vec && b_kc == b_kc0;
-        p.tiles_m = cgn_cdiv(d->M, 64);
+        if (fk0 < 0) fk0 = p.fastk;
+        x6g = x6g && d->compute == CGN_COMPUTE_F32X6 && x6_variant_exists(p, a_kc, b_kc) && a_kc == a_kc0 && b_kc == b_kc0 &&
+              p.fastk == fk0 && d->M >= 256 && d->N >= 256 && !(a_kc0 == false && b_kc0 == true);
+        big_x6 = big_x6 || (d->compute == CGN_COMPUTE_F32X6 && x6_variant_exists(p, a_kc, b_kc) && d->M >= 256 && d->N >= 256);
+        p.tiles_m = cgn_cdiv(d->M, 64);  // (re-tiled below for an X6 group)
         p.tiles_n = cgn_cdiv(d->N, 64);
         p.splitk = 1;
         p.k_per_split = cgn_cdiv(d->K > 0 ? d->K : 1, KROUND) * KROUND;
@@ -381,10 +388,28 @@ extern "C" int cgn_gemm_group_f32(void* stream, const cgn_gemm_desc* descs, int3
         ++g.n;
     }
     if (g.n == 0) return CGN_OK;
+    if (!x6g && !bf16 && big_x6) {
+        // X6 products that do not share one kernel variant: the 64-tile fp32 group kernel would be the slower choice
+        for (int i = 0; i < n; ++i) {
+            const int rc = run_gemm(stream, descs + i, nullptr, nullptr);
+            if (rc) return rc;
+        }
+        return CGN_OK;
+    }
+    if (x6g) {
+        tiles_total = 0;
+        for (int i = 0; i < g.n; ++i) {
+            g.p[i].tiles_m = cgn_cdiv(g.p[i].M, 128);
+            g.p[i].tiles_n = cgn_cdiv(g.p[i].N, 128);
+            tiles_total += (long)g.p[i].tiles_m * g.p[i].tiles_n;
+        }
+    }
     // K split: a group with few tiles (the text-CNN: ~100 tiles of 30-50 K steps) is a latency chain on a fraction of
     // the CUs; split every member so that ~768 blocks exist, each keeping >= 4 K steps. Slabs are carved out of the
     // first member's workspace; without room the group runs unsplit.
     int want = tiles_total >= 384 ? 1 : (int)((768 + tiles_total - 1) / tiles_total);
+    const int min_k = x6g ? 512 : 128;  // (X6 128-tile: 512 resident slots, splits below K = 512 lose in the step)
+    if (x6g) want = tiles_total >= 256 ? 1 : (int)((512 + tiles_total - 1) / tiles_total);
     if (want > 64) want = 64;  // (each member is further limited to K / 128 splits below)
     long ws_off = 0;
     bool any_split = false;
@@ -393,7 +418,7 @@ extern "C" int cgn_gemm_group_f32(void* stream, const cgn_gemm_desc* descs, int3
         for (int i = 0; i < g.n; ++i) {
             GemmParams& p = g.p[i];
             int sk = want;
-            if (sk > p.K / 128) sk = p.K / 128;
+            if (sk > p.K / min_k) sk = p.K / min_k;
             if (sk < 1) sk = 1;
             const int kps = cgn_cdiv(cgn_cdiv(p.K > 0 ? p.K : 1, sk), KROUND) * KROUND;
             sk = p.K > 0 ? cgn_cdiv(p.K, kps) : 1;
@@ -424,6 +449,8 @@ extern "C" int cgn_gemm_group_f32(void* stream, const cgn_gemm_desc* descs, int3
     const int vec = (va ? 1 : 0) | (vb ? 2 : 0);
     if (bf16)
         launch_group_bf16ops(g, vec, a_kc0, b_kc0, (unsigned)blocks, s);
+    else if (x6g)
+        launch_group_x6(g, a_kc0, b_kc0, fk0, (unsigned)blocks, s);
     else
         launch_group_f32ops(g, vec, a_kc0, b_kc0, (unsigned)blocks, s);
     CGN_LAUNCH_CHECK();

@@ -1102,14 +1102,15 @@ struct GemmGroup {
     int n;
 };
 
-template <int BT, bool A_KC, bool B_KC, int VEC, int S, int BK = (BT == 128 ? 16 : 32), bool BF = false, int FK = 0>
+template <int BT, bool A_KC, bool B_KC, int VEC, int S, int BK = (BT == 128 ? 16 : 32), bool BF = false, int FK = 0,
+          bool X6 = false>
 __global__ __launch_bounds__(NT, 2) void gemm_group_kernel(const GemmGroup g) {
     int j = 0;
     while (j + 1 < g.n && (int)blockIdx.x >= g.tile_end[j]) ++j;  // block-uniform
     const int local = blockIdx.x - (j ? g.tile_end[j - 1] : 0);  // (split, tile) of member j, tile fastest
     const int ntiles = g.p[j].tiles_m * g.p[j].tiles_n;
     const int split = local / ntiles;
-    gemm_tile<BT, A_KC, B_KC, VEC, false, S, BK, false, BF, FK>(g.p[j], split, local - split * ntiles);
+    gemm_tile<BT, A_KC, B_KC, VEC, false, S, BK, false, BF, FK, false, X6>(g.p[j], split, local - split * ntiles);
 }
 
 // Sums the split-K slabs in fixed order z = 0..splitk-1 (bitwise reproducible). Slab rows are ldw = ceil4(N) floats
@@ -1288,6 +1289,26 @@ bool launch_x6_t(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream
     return true;
 }
 
+// X6 grouped launch (128-tile; gemm_x6.hip): sibling products that each leave most of the chip idle - the encoder's two
+// W_ih products, the per-direction / per-layer dW products - as ONE launch. fk: the members' common fast-K mode.
+inline bool launch_group_x6_t(const GemmGroup& g, bool a_kc, bool b_kc, int fk, unsigned blocks, hipStream_t s) {
+    if (fk == 2) {
+        if (a_kc || b_kc) return false;
+        hipLaunchKernelGGL((gemm_group_kernel<128, false, false, 3, 2, 16, true, 2, true>), dim3(blocks), dim3(NT), 0, s, g);
+        return true;
+    }
+    if (fk != 1) return false;
+    if (a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_group_kernel<128, true, true, 3, 2, 16, true, 1, true>), dim3(blocks), dim3(NT), 0, s, g);
+    else if (a_kc && !b_kc)
+        hipLaunchKernelGGL((gemm_group_kernel<128, true, false, 3, 2, 16, true, 1, true>), dim3(blocks), dim3(NT), 0, s, g);
+    else if (!a_kc && !b_kc)
+        hipLaunchKernelGGL((gemm_group_kernel<128, false, false, 3, 2, 16, true, 1, true>), dim3(blocks), dim3(NT), 0, s, g);
+    else
+        return false;
+    return true;
+}
+
 template <int VEC, bool BF, int FK>
 void launch_group_vk(const GemmGroup& g, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s) {
     constexpr int BK = bk_of<64, BF>();
@@ -1333,6 +1354,7 @@ void launch_gemm_f32ops(const GemmParams& p, int bt, bool a_kc, bool b_kc, dim3 
 void launch_gemm_bf16ops(const GemmParams& p, int bt, bool a_kc, bool b_kc, dim3 grid, hipStream_t s);
 void launch_gemm_a16(const GemmParams& p, int bt, bool b_kc, dim3 grid, hipStream_t s);
 bool launch_gemm_x6(const GemmParams& p, int bt, bool a_kc, bool b_kc, dim3 grid, hipStream_t s);
+bool launch_group_x6(const GemmGroup& g, bool a_kc, bool b_kc, int fk, unsigned blocks, hipStream_t s);
 void launch_group_f32ops(const GemmGroup& g, int vec, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s);
 void launch_group_bf16ops(const GemmGroup& g, int vec, bool a_kc, bool b_kc, unsigned blocks, hipStream_t s);
 }  // namespace cgn_gemm

@@ -8,4 +8,7 @@ namespace cgn_gemm {
 bool launch_gemm_x6(const GemmParams& p, int bt, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
     return bt == 128 ? launch_x6_t<128>(p, a_kc, b_kc, grid, s) : launch_x6_t<64>(p, a_kc, b_kc, grid, s);
 }
+bool launch_group_x6(const GemmGroup& g, bool a_kc, bool b_kc, int fk, unsigned blocks, hipStream_t s) {
+    return launch_group_x6_t(g, a_kc, b_kc, fk, blocks, s);
+}
 }  // namespace cgn_gemm

@@ -269,6 +269,35 @@ def lstm_param_grads(seq, dgates, x_operand, dW_ih, dW_hh, db_ih, db_hh, beta=0.
     return dg2
 
 
+def lstm_param_grads_multi(items, beta=0.0):
+    """lstm_param_grads for several sequences / layers at once: items = [(seq, dgates, x_operand, dW_ih, dW_hh, db_ih,
+    db_hh), ...]. The weight-gradient products of one kind (over plain x rows; over [B,T+1,H] history buffers) go out as
+    ONE grouped launch each (cgn_gemm_group_f32: an X6 128-tile group where every member qualifies, else the library
+    issues them one by one): a 2048 x 512 x 1344 product alone has 64-128 workgroups for 256 CUs."""
+    plain, hist = [], []
+    for seq, dgates, (xt, xk), dW_ih, dW_hh, db_ih, db_hh in items:
+        B, T, H = seq.B, seq.T, seq.H
+        dg2 = dgates.view(B * T, 4 * H)
+        if dW_ih is not None:
+            (hist if xk.rpg else plain).append((dg2.t(), xt, dW_ih, dict(N=dW_ih.shape[1], K=B * T, b_k=xk, b_n=LIN,
+                                                                         beta=beta)))
+        hp, hk = seq.hprev_operand()
+        hist.append((dg2.t(), hp, dW_hh, dict(N=H, K=B * T, b_k=hk, b_n=LIN, beta=beta)))
+    for calls in (hist, plain):
+        if len(calls) == 1:
+            a, b, out, kw = calls[0]
+            ops.gemm(a, b, out, **kw)
+        elif calls:
+            ops.gemm_group(calls)
+    for seq, dgates, _, _, _, db_ih, db_hh in items:
+        dg2 = dgates.view(seq.B * seq.T, 4 * seq.H)
+        ops.colsum(dg2, db_ih, beta=beta)
+        if beta == 0.0:
+            ops.copy2d(db_ih.view(1, -1), db_hh.view(1, -1))
+        else:
+            ops.colsum(dg2, db_hh, beta=beta)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # text-CNN discriminator (model/discriminator_sentiment.py:56-78)
 # ------------------------------------------------------------------------------------------------------------------

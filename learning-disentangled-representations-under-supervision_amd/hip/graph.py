@@ -172,6 +172,8 @@ class GraphedWakeSleep:
                 torch.cuda.synchronize(eng.dev)
             finally:
                 ops.KEEP = None
+            from .. import parallel
+            parallel.quiesce_before_capture(eng.dev)  # (RCCL watchdog vs. capture: see there)
             ops.KEEP = []
             try:
                 with ops.capture_without_gc():  # a collector run inside a capture can abort the process (ops.py)

@@ -116,6 +116,8 @@ class BeamSampler:
             self._token_step(st, False, eos, pad)
         torch.cuda.current_stream(dev).wait_stream(stream)
         torch.cuda.synchronize(dev)
+        from .. import parallel
+        parallel.quiesce_before_capture(dev)  # (RCCL watchdog vs. capture: see there)
         graphs, outs = [], []
         prev_keep, ops.KEEP = ops.KEEP, []
         try:

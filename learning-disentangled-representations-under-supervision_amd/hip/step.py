@@ -25,7 +25,14 @@ LIN = Axis(1, 0, 0)
 # plan of every product issued there; CGN_HW_DW_EARLY=1 forks the highway's dW products where their inputs are ready
 TAIL_HINT = {k: int(os.environ[e]) for k, e in (("splitk", "CGN_TAIL_SPLITK"), ("tile", "CGN_TAIL_TILE"))
              if os.environ.get(e)}
-HW_DW_EARLY = os.environ.get("CGN_HW_DW_EARLY") == "1"
+HW_DW_EARLY = os.environ.get("CGN_HW_DW_EARLY", "1") != "0"
+# sibling products (the encoder's two W_ih products, the per-direction / per-layer LSTM weight-gradient products) as
+# grouped X6 launches (cgn_gemm_group_f32); CGN_GROUP_SIBLINGS=0: one launch per product (A/B switch)
+GROUP_SIBLINGS = os.environ.get("CGN_GROUP_SIBLINGS", "1") != "0"
+# ... and the weight-gradient products in the step's tail too. Off: measured +35 us per step (2.56 against 2.525 ms, same
+# box, profiles/r03_group_ab.txt) - one 400-block launch per stream shares the chip worse with the other two streams'
+# work than a few 128-block launches do
+GROUP_TAIL = os.environ.get("CGN_GROUP_TAIL", "0") == "1"
 SOFTEMB_TILE = int(os.environ.get("CGN_SOFTEMB_TILE", "0"))
 SOFTEMB_SPLITK = int(os.environ.get("CGN_SOFTEMB_SPLITK", "0"))
 
@@ -404,10 +411,15 @@ class CGNStep:
         hw_out, hw_saved = engine.highway_fwd(enc_in, self._hw_layers(P))
         ops.stamp("M highway fwd done")
         sf, sr = engine.LstmSeq(B, L, He, self.dev, False), engine.LstmSeq(B, L, He, self.dev, True)
-        for s, sfx in ((sf, ""), (sr, "_reverse")):
-            ops.gemm(hw_out, P["encoder.rnn.weight_ih_l0" + sfx].t(), s.xg.view(N, 4 * He),
-                     bias0=P["encoder.rnn.bias_ih_l0" + sfx], bias1=P["encoder.rnn.bias_hh_l0" + sfx])
-            s.set_initial()
+        calls = [(hw_out, P["encoder.rnn.weight_ih_l0" + sfx].t(), s.xg.view(N, 4 * He),
+                  dict(bias0=P["encoder.rnn.bias_ih_l0" + sfx], bias1=P["encoder.rnn.bias_hh_l0" + sfx]))
+                 for s, sfx in ((sf, ""), (sr, "_reverse"))]
+        if GROUP_SIBLINGS and ops.get_compute() == "f32" and ops.GEMM_X6:
+            ops.gemm_group(calls)  # both directions in one launch: 160 tiles each would leave a third of the CUs idle
+        else:
+            for a_, b_, o_, kw in calls:
+                ops.gemm(a_, b_, o_, **kw)
+        sf.set_initial(), sr.set_initial()
         # No exclusive() here: the only work that can still be running is the tail of the discriminator step / c inference
         # on side stream 0, a chain of kernels with 1-113 workgroups that fit beside the recurrence's 256 (measured: the
         # join cost 54 us per step, the chain's last ~80 us ran with the whole GPU waiting; beside the launch it is free).
@@ -472,11 +484,14 @@ class CGNStep:
             # parameter gradients leave the critical path (dX chain) when streams overlap
             if ops.STAMPS is not None:
                 self.later(0, lambda: ops.stamp("S0 deferred work begins (encoder LSTM dW)"))
-            for s, dg, sfx in ((sf, dgf, ""), (sr, dgr, "_reverse")):
-                self.later(0, lambda s=s, dg=dg, sfx=sfx: engine.lstm_param_grads(
-                    s, dg, (hw_out, Axis(hw_out.stride(0), 0, 0)), G["encoder.rnn.weight_ih_l0" + sfx],
-                    G["encoder.rnn.weight_hh_l0" + sfx], G["encoder.rnn.bias_ih_l0" + sfx],
-                    G["encoder.rnn.bias_hh_l0" + sfx]))
+            items = [(s, dg, (hw_out, Axis(hw_out.stride(0), 0, 0)), G["encoder.rnn.weight_ih_l0" + sfx],
+                      G["encoder.rnn.weight_hh_l0" + sfx], G["encoder.rnn.bias_ih_l0" + sfx],
+                      G["encoder.rnn.bias_hh_l0" + sfx]) for s, dg, sfx in ((sf, dgf, ""), (sr, dgr, "_reverse"))]
+            if GROUP_TAIL and ops.get_compute() == "f32" and ops.GEMM_X6:
+                self.later(0, lambda: engine.lstm_param_grads_multi(items))
+            else:
+                for it in items:
+                    self.later(0, lambda it=it: engine.lstm_param_grads(*it))
             # The step's last LSTM launch is behind us: what later() queued forks here. (Inside ONE captured graph a node
             # with three successors - main and both side streams - replayed wrongly on ROCm 7.2: the dX GEMM below ran
             # on unfinished LSTM gradients (tools/graph_diff.py). The in-graph form therefore forks side stream 1 here
@@ -773,9 +788,11 @@ class CGNStep:
             ops.fill(dc0, 0.0)
             self.exclusive()
             (dg0,) = engine.lstm_run_bwd([g0], [P["generator.rnn.weight_hh_l0"]], [(dH0, T * Hg, Hg)], [None], [dc0])
-        self.later(1, lambda: engine.lstm_param_grads(g1, dg1, (h0, h0ax), G["generator.rnn.weight_ih_l1"],
-                                                      G["generator.rnn.weight_hh_l1"], G["generator.rnn.bias_ih_l1"],
-                                                      G["generator.rnn.bias_hh_l1"]))
+        group_gen = GROUP_TAIL and ops.get_compute() == "f32" and ops.GEMM_X6
+        item1 = (g1, dg1, (h0, h0ax), G["generator.rnn.weight_ih_l1"], G["generator.rnn.weight_hh_l1"],
+                 G["generator.rnn.bias_ih_l1"], G["generator.rnn.bias_hh_l1"])
+        if not group_gen:
+            self.later(1, lambda: engine.lstm_param_grads(*item1))
         ops.stamp("M generator LSTM bwd done")
         dWih0 = G["generator.rnn.weight_ih_l0"]
         dsum = _new((B, 4 * Hg), dev)
@@ -789,10 +806,12 @@ class CGNStep:
                               dc_enc[1], dyn=self._dyn(2))
         else:
             ops.sum_time(dg0, dsum)
-        self.later(1, lambda: (engine.lstm_param_grads(g0, dg0, (gen_emb, Axis(E, 0, 0)), dWih0[:, :E],
-                                                       G["generator.rnn.weight_hh_l0"], G["generator.rnn.bias_ih_l0"],
-                                                       G["generator.rnn.bias_hh_l0"]),
-                               ops.gemm(dsum.t(), zc, dWih0[:, E:])))
+        item0 = (g0, dg0, (gen_emb, Axis(E, 0, 0)), dWih0[:, :E], G["generator.rnn.weight_hh_l0"],
+                 G["generator.rnn.bias_ih_l0"], G["generator.rnn.bias_hh_l0"])
+        if group_gen:  # both layers' weight-gradient products over the history buffers as one launch
+            self.later(1, lambda: (engine.lstm_param_grads_multi([item1, item0]), ops.gemm(dsum.t(), zc, dWih0[:, E:])))
+        else:
+            self.later(1, lambda: (engine.lstm_param_grads(*item0), ops.gemm(dsum.t(), zc, dWih0[:, E:])))
         if not fused_head_bwd:
             ops.gemm(dsum, Wih0[:, E:], dzc)  # g = dzc[:, :Z] = d(79*CE + recon)/dz  (cgn.py:1099, 1142)
         if capture is not None:

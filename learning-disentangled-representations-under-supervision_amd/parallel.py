@@ -78,6 +78,19 @@ class BucketedAllReduce:
         self.wait(self.begin(flat))
 
 
+def quiesce_before_capture(device=None):
+    """Call before ANY hipGraph capture in a process that has an RCCL process group. ProcessGroupNCCL's watchdog thread
+    polls the end event of every collective it has not yet seen complete (hipEventQuery, every 100 ms); on ROCm 7.2 such
+    a query fails with hipErrorCapturedEvent while the stream the event was last recorded on is being captured - even for
+    an event recorded long before the capture began - and the watchdog then terminates the process (seen once in ~10 runs
+    of tests/test_graph_gpu.py: the eager warm-up step's collectives were still on the watchdog's list when the capture
+    of the same streams started). Draining the device and giving the watchdog a few polls empties its list."""
+    if dist.is_available() and dist.is_initialized() and torch.cuda.is_available():
+        import time
+        torch.cuda.synchronize(device)
+        time.sleep(0.5)
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract).
     Returns (rank, world_size, local_rank)."""

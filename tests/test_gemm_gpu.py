@@ -569,3 +569,44 @@ def test_gemm_fused_statistics_are_refused_where_no_kernel_serves_them(dev):
     d.ep_stats, d.ep_stats_ld = out.data_ptr(), 5
     with pytest.raises(RuntimeError, match="invalid argument"):
         _lib.check(_lib.load().cgn_gemm_f32(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(d)), "cgn_gemm_f32")
+
+
+@pytest.mark.parametrize("kind", ["nt", "nn", "tn", "tn_history", "mixed"])
+def test_gemm_x6_group(dev, kind):
+    """Sibling X6 products in one 128-tile launch (the encoder's two W_ih products, the per-layer LSTM weight gradients
+    over history buffers): each member equals its own single launch bit for bit where the plan is the same, and the fp64
+    product to 2e-6 always; a group whose members do not share a kernel variant ("mixed") is issued member by member."""
+    ops = _ops()
+    from ldrs_amd.hip._lib import Axis
+    g = torch.Generator().manual_seed(11)
+    calls, refs, outs = [], [], []
+    if kind == "tn_history":
+        Bn, T, H = 24, 20, 64
+        for i in range(3):
+            dg, hbuf = _mk((Bn, T, 4 * H), g), _mk((Bn, T + 1, H), g)
+            refs.append(dg.double().reshape(Bn * T, 4 * H).t() @ hbuf[:, :T].double().reshape(Bn * T, H))
+            out = torch.full((4 * H, H), float("nan"), device=dev)
+            outs.append(out)
+            calls.append((dg.to(dev).view(Bn * T, 4 * H).t(), hbuf.to(dev), out,
+                          dict(N=H, K=Bn * T, b_k=Axis(H, T, (T + 1) * H), b_n=Axis(1, 0, 0))))
+    else:
+        for i in range(3):
+            layout = ("nt", "nn", "tn")[i] if kind == "mixed" else kind
+            M, N, K = 256 + 132 * i, 384 - 64 * i, 512 + 96 * i
+            A, B = _mk((M, K), g), _mk((K, N), g)
+            bias = _mk((N,), g).to(dev)
+            a = A.to(dev) if layout[0] == "n" else A.t().contiguous().to(dev).t()
+            b = B.to(dev) if layout[1] == "n" else B.t().contiguous().to(dev).t()
+            out = torch.full((M, N), float("nan"), device=dev)
+            calls.append((a, b, out, dict(bias0=bias)))
+            refs.append(A.double() @ B.double() + bias.cpu().double())
+            outs.append(out)
+    ops.gemm_group([(a, b, o, dict(kw, compute="f32x6")) for a, b, o, kw in calls])
+    torch.cuda.synchronize()
+    for out, ref in zip(outs, refs):
+        assert _rel(out, ref) < 2e-6
+    if kind == "mixed":  # issued member by member: exactly the single launches
+        for (a, b, o, kw), out in zip(calls, outs):
+            single = torch.empty_like(out)
+            ops.gemm(a, b, single, compute="f32x6", **kw)
+            assert torch.equal(single, out)

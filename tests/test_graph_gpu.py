@@ -92,6 +92,7 @@ def one_rank_group(dev):
     torch.cuda.set_device(dev)
     dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
     yield
+    torch.cuda.synchronize()  # no collective may be in flight (or on the watchdog's list) when the group goes away
     dist.destroy_process_group()
 
 
