@@ -147,6 +147,7 @@ class GraphedWakeSleep:
         # ring of pinned scalar blocks: the async H2D copy of step n may still be queued when the host prepares n+1
         self.pinned = torch.zeros(256, 4, dtype=torch.float32).pin_memory()
         self.calls = 0
+        self._sticky_host = None
         self.branches = None  # per-branch graphs (single-GPU overlapped replay), see _BranchRecorder
         self.stream = torch.cuda.Stream(eng.dev)
         self.graph = torch.cuda.CUDAGraph()
@@ -267,6 +268,35 @@ class GraphedWakeSleep:
     def _run(self):
         return self.eng.wake_sleep(self.opts, self.static, 0.0, 1.0, calc_z_loss=self.calc_z)
 
+    # A persistent LSTM launch whose bounded wait ran out leaves a sticky device word (include/cgn_hip.h); every replay
+    # after it trains on invalid activations. A caller that never synchronises (no logging) would learn of it only at the
+    # end of its loop, so every STICKY_EVERY-th replay copies the words to pinned host memory behind itself (async, no
+    # synchronisation) and every call looks at what earlier copies brought back: the loop stops at most
+    # 2 * STICKY_EVERY replays after the launch that timed out.
+    STICKY_EVERY = 8
+
+    def _watch_sticky(self):
+        if self.calls % self.STICKY_EVERY:
+            return
+        dev = self.eng.dev
+        didx = dev.index if dev.index is not None else torch.cuda.current_device()
+        bufs = [ws for (idx, _), ws in ops._lstm_sync.items() if idx == didx]
+        if not bufs:
+            return
+        if self._sticky_host is None or self._sticky_host.numel() != len(bufs):
+            self._sticky_host = torch.zeros(len(bufs), dtype=torch.int32).pin_memory()
+        for i, ws in enumerate(bufs):
+            self._sticky_host[i:i + 1].copy_(ws[-32:-31], non_blocking=True)
+
+    def _check_sticky(self):
+        h = self._sticky_host
+        if h is not None and bool(h.any()):
+            h.zero_()  # (the next watch copy brings the device word back if it is still set)
+            raise ops.LstmTimeoutError(
+                "a persistent LSTM launch ran out of a bounded wait some replays ago (sticky flag seen by the replay "
+                "loop's asynchronous watch): activations since then are invalid. Reload the last checkpoint and rerun "
+                "with CGN_LSTM_PERSISTENT=0 (ops.clear_lstm_sticky_timeouts() re-arms the persistent kernels).")
+
     def _bump_host_steps(self):
         for st in self.opts.values():
             st.step += 1
@@ -290,6 +320,7 @@ class GraphedWakeSleep:
         # collective that waits for a side stream's gradients then blocks the queue's head, and with it the whole main
         # chain (measured: the dX chain started 620 us late, --force-dp 3.38 ms against 2.98 ms; on its own stream
         # [queue 1, idle otherwise] the main chain shares a queue with nothing).
+        self._check_sticky()
         cur = torch.cuda.current_stream(eng.dev)
         own = cur.cuda_stream != self.stream.cuda_stream
         if own:
@@ -301,6 +332,7 @@ class GraphedWakeSleep:
             for i, (g, actions) in enumerate(self.segments or ()):  # (one graph: overlap off, or branch_graphs=False)
                 self.progress = (self.calls, i, "replay")
                 g.replay()
+            self._watch_sticky()
         if own:
             cur.wait_stream(self.stream)
         self.progress = (self.calls, "-", "done")

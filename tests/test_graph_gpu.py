@@ -70,6 +70,35 @@ def test_graph_replay_trains_like_eager(dev, calc_z, overlap):
         assert err <= 2e-6, (n, err)  # device-side vs host-side double pow() in Adam's bias correction
 
 
+def test_replay_loop_notices_a_timed_out_persistent_launch_without_synchronising(dev):
+    """A caller that replays and never reads a loss back still stops: every 8th replay copies the persistent kernels'
+    sticky words to pinned host memory behind itself, every call looks at what came back (hip/graph.py). The word is
+    forced here (a healthy GPU never sets it)."""
+    from ldrs_amd.hip import ops
+    from ldrs_amd.hip.graph import GraphedWakeSleep
+    _, eng, opts, ocfg = _build(dev)
+    data = _batches(ocfg, dev, 1)
+    g = GraphedWakeSleep(eng, opts, data[0])
+    for _ in range(3):
+        g(0.5, 1.0)
+    if not ops._lstm_sync:
+        pytest.skip("this shape does not take the persistent kernels")
+    try:
+        for ws in ops._lstm_sync.values():
+            ws[-32] = 1
+        with pytest.raises(ops.LstmTimeoutError):
+            for _ in range(2 * GraphedWakeSleep.STICKY_EVERY + 2):
+                g(0.5, 1.0)
+                torch.cuda.synchronize()  # (only so that the test does not depend on how far the host runs ahead)
+    finally:
+        ops.clear_lstm_sticky_timeouts()
+    torch.cuda.synchronize()
+    for _ in range(2 * GraphedWakeSleep.STICKY_EVERY + 2):  # re-armed: the loop runs again
+        g(0.5, 1.0)
+    torch.cuda.synchronize()
+    assert ops.lstm_sticky_timeouts() == 0
+
+
 def test_graph_rejects_other_shapes(dev):
     from ldrs_amd.hip.graph import GraphedWakeSleep
     _, eng, opts, ocfg = _build(dev)
