@@ -206,6 +206,14 @@ typedef struct cgn_lstm_fwd_seq {
 int cgn_lstm_seq_fwd_f32(void* stream, const cgn_lstm_fwd_seq* seqs /* host */, int32_t nseq, int32_t B, int32_t T,
                          int32_t H);
 
+/* Operand mode of the recurrences, process-wide (read at launch time; a captured hipGraph keeps the kernels it was
+ * captured with): 0 (default) = every recurrent product at fp32 accuracy (fp32 MFMA, or X6 where the three-term weight
+ * slice fits the registers: H <= 512); 1 = the optional bf16 mode (north_star: <= 1e-2): the row-tiled persistent
+ * kernels at H > 512 form h.W_hh^T / dgates.W_hh from TWO-term bf16 splits of both operands (a0b0 + a0b1 + a1b0 on
+ * v_mfma_f32_16x16x32_bf16, fp32 accumulation, ~2^-16 relative per product; the two-term weight slice takes the same
+ * 128 registers as the fp32 one). No counterpart in the reference (nn.LSTM, model/encoder.py:17-21, generator.py:17-20). */
+int cgn_lstm_set_operand_mode(int32_t mode);
+
 /* Persistent form of the two recurrences: ONE launch runs all T timesteps with the workgroup's W_hh slice, c_t / dc_t
  * held in registers; the workgroups sharing a batch tile hand h_t (dgates_t) over through write-through stores and a
  * per-group arrival counter (csrc/lstm.hip). Replaces the same reference call sites as cgn_lstm_seq_fwd/bwd_f32

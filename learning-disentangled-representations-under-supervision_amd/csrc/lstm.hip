@@ -399,14 +399,19 @@ __device__ __forceinline__ Frag3 split3(const f32x4& u, const f32x4& v) {
 }
 #define CGN_MFMA_BF16(A_, B_, C_) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A_), (B_), (C_), 0, 0, 0)
 // NG accumulators that share the A operand (the four gates): term-major, so consecutive MFMAs are independent
-template <int NG>
+// NP = 3: the six products above (fp32 accuracy). NP = 2 ("X3", the optional bf16 mode's row-tiled recurrences at
+// H > 512, cgn_lstm_set_operand_mode): two-term operands, a0b0 + a0b1 + a1b0, ~2^-16 relative per product - 250x finer
+// than bf16 operands, half the registers of the three-term weight slice (the same 128 VGPRs as the fp32 slice at H = 1024).
+template <int NG, int NP = 3>
 __device__ __forceinline__ void mfma_x6(const Frag3& a, const Frag3 (&b)[NG], f32x4 (&acc)[NG]) {
+    if constexpr (NP == 3) {
 #pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = CGN_MFMA_BF16(a.p0, b[g].p2, acc[g]);
+        for (int g = 0; g < NG; ++g) acc[g] = CGN_MFMA_BF16(a.p0, b[g].p2, acc[g]);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = CGN_MFMA_BF16(a.p2, b[g].p0, acc[g]);
+        for (int g = 0; g < NG; ++g) acc[g] = CGN_MFMA_BF16(a.p2, b[g].p0, acc[g]);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = CGN_MFMA_BF16(a.p1, b[g].p1, acc[g]);
+        for (int g = 0; g < NG; ++g) acc[g] = CGN_MFMA_BF16(a.p1, b[g].p1, acc[g]);
+    }
 #pragma unroll
     for (int g = 0; g < NG; ++g) acc[g] = CGN_MFMA_BF16(a.p0, b[g].p1, acc[g]);
 #pragma unroll
@@ -415,10 +420,13 @@ __device__ __forceinline__ void mfma_x6(const Frag3& a, const Frag3 (&b)[NG], f3
     for (int g = 0; g < NG; ++g) acc[g] = CGN_MFMA_BF16(a.p0, b[g].p0, acc[g]);
 }
 // one accumulator chain (backward kernels: two chains, even / odd chunk pairs)
+template <int NP = 3>
 __device__ __forceinline__ f32x4 mfma_x6(const Frag3& a, const Frag3& b, f32x4 acc) {
-    acc = CGN_MFMA_BF16(a.p0, b.p2, acc);
-    acc = CGN_MFMA_BF16(a.p2, b.p0, acc);
-    acc = CGN_MFMA_BF16(a.p1, b.p1, acc);
+    if constexpr (NP == 3) {
+        acc = CGN_MFMA_BF16(a.p0, b.p2, acc);
+        acc = CGN_MFMA_BF16(a.p2, b.p0, acc);
+        acc = CGN_MFMA_BF16(a.p1, b.p1, acc);
+    }
     acc = CGN_MFMA_BF16(a.p0, b.p1, acc);
     acc = CGN_MFMA_BF16(a.p1, b.p0, acc);
     acc = CGN_MFMA_BF16(a.p0, b.p0, acc);
@@ -715,9 +723,11 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdPara
 // 32 KB reduction buffer; hand-off, counters and timeouts are those of the kernels above (one group = the workgroups
 // that share a 16RT-row batch tile). RT = 1, H <= 512 keeps the kernels above.
 // ------------------------------------------------------------------------------------------------------------------
-template <int CPW, int RT, bool X6>
+template <int CPW, int RT, int XM>  // XM: 0 = fp32 MFMA, 3 = X6, 2 = X3 (two-term operands: the bf16 mode, H > 512)
 __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdParams p, unsigned* sync, unsigned* sticky) {
-    static_assert(CPW % 2 == 0 && (!X6 || CPW <= 4), "X6: chunk pairs; the split weight slice of H = 1024 does not fit the registers");
+    constexpr bool X6 = XM != 0;
+    static_assert(XM == 0 || XM == 2 || XM == 3, "operand mode");
+    static_assert(CPW % 2 == 0 && (XM != 3 || CPW <= 4), "X6: chunk pairs; the three-term weight slice of H = 1024 does not fit the registers");
     __shared__ float red[LSTM_NW][16][64];
     __shared__ int s_ok;
     const int B = p.B, T = p.T, H = p.H;
@@ -824,7 +834,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdP
                 for (int u = 0; u < CPW; ++u) a[u] = ld4_sc1(hres, hoff + koff[u]);
                 if constexpr (X6) {
 #pragma unroll
-                    for (int u = 0; u < CPW; u += 2) mfma_x6<4>(split3(a[u], a[u + 1]), w3[u / 2], acc);
+                    for (int u = 0; u < CPW; u += 2) mfma_x6<4, XM == 2 ? 2 : 3>(split3(a[u], a[u + 1]), w3[u / 2], acc);
                 } else {
 #pragma unroll
                     for (int u = 0; u < CPW; ++u) {
@@ -879,11 +889,12 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdP
 
 // CPW: chunks (of 16 k over K = 4H) per wave held in registers (H <= 32 * CPW); the gradient rows are loaded CB chunks at
 // a time (32 VGPRs) so that the 128-VGPR weight slice of H = 1024 leaves room for them.
-template <int CPW, int RT, bool X6>
+template <int CPW, int RT, int XM>  // XM: 0 = fp32 MFMA, 3 = X6, 2 = X3 (two-term operands: the bf16 mode, H > 512)
 __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_rt_kernel(const BwdParams p, unsigned* sync, unsigned* sticky) {
+    constexpr bool X6 = XM != 0;
     constexpr int CB = CPW < 8 ? CPW : 8;
     static_assert(CPW % CB == 0 && CB % 4 == 0, "chunk batches; two accumulator chains over chunk pairs");
-    static_assert(!X6 || CPW <= 16, "the split weight slice of H = 1024 does not fit the registers");
+    static_assert(XM == 0 || XM == 2 || (XM == 3 && CPW <= 16), "the three-term weight slice of H = 1024 does not fit the registers");
     __shared__ float red[LSTM_NW][4][64];
     __shared__ int s_ok;
     const int B = p.B, T = p.T, H = p.H;
@@ -977,8 +988,8 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_rt_kernel(const BwdP
                     if constexpr (X6) {
 #pragma unroll
                         for (int u = 0; u < CB; u += 4) {
-                            acc0 = mfma_x6(split3(a[u], a[u + 1]), w3[(c0 + u) / 2], acc0);
-                            acc1 = mfma_x6(split3(a[u + 2], a[u + 3]), w3[(c0 + u) / 2 + 1], acc1);
+                            acc0 = mfma_x6<XM == 2 ? 2 : 3>(split3(a[u], a[u + 1]), w3[(c0 + u) / 2], acc0);
+                            acc1 = mfma_x6<XM == 2 ? 2 : 3>(split3(a[u + 2], a[u + 3]), w3[(c0 + u) / 2 + 1], acc1);
                         }
                     } else {
 #pragma unroll
@@ -1449,6 +1460,10 @@ int g_num_cus[16] = {0};
 // consumer wave splits its share again (64 values per lane and step: ~1 us of VALU work on a SIMD that two waves
 // share), which eats the MFMA time saved. (Splitting once at the producer and handing the bf16 parts over is the
 // next step.) CGN_LSTM_X6=0 / CGN_LSTM_X6_BWD=1 override (A/B measurements).
+// 0 = every recurrence at fp32 accuracy (default); 1 = the optional bf16 mode: the row-tiled recurrences at H > 512 take
+// two-term bf16 operands (cgn_lstm_set_operand_mode, include/cgn_hip.h)
+int g_lstm_operand_mode = 0;
+
 bool lstm_x6() {
     static const bool v = [] { const char* e = getenv("CGN_LSTM_X6"); return !(e && e[0] == '0'); }();
     return v;
@@ -1623,16 +1638,19 @@ extern "C" int cgn_lstm_seq_fwd_persistent_f32(void* stream, const cgn_lstm_fwd_
 #define CGN_FWD_K(CPW) do { if (x6) hipLaunchKernelGGL((lstm_persist_fwd_kernel<CPW, true>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky); \
                             else hipLaunchKernelGGL((lstm_persist_fwd_kernel<CPW, false>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky); } while (0)
 #define CGN_FWD_RT(CPW, RT, X) hipLaunchKernelGGL((lstm_persist_fwd_rt_kernel<CPW, RT, X>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky)
-#define CGN_FWD_RTX(CPW, RT) do { if (x6) CGN_FWD_RT(CPW, RT, true); else CGN_FWD_RT(CPW, RT, false); } while (0)
+#define CGN_FWD_RTX(CPW, RT) do { if (x6) CGN_FWD_RT(CPW, RT, 3); else CGN_FWD_RT(CPW, RT, 0); } while (0)
+    // H > 512: the three-term weight slice does not fit the registers; the two-term one does (the bf16 mode only)
+#define CGN_FWD_RTB(CPW, RT) do { if (g_lstm_operand_mode == 1) CGN_FWD_RT(CPW, RT, 2); else CGN_FWD_RT(CPW, RT, 0); } while (0)
     if (rt == 1 && H <= 256) CGN_FWD_K(2);
     else if (rt == 1 && H <= 512) CGN_FWD_K(4);
-    else if (rt == 1) CGN_FWD_RT(8, 1, false);
+    else if (rt == 1) CGN_FWD_RTB(8, 1);
     else if (rt == 2 && H <= 256) CGN_FWD_RTX(2, 2);
     else if (rt == 2 && H <= 512) CGN_FWD_RTX(4, 2);
-    else if (rt == 2) CGN_FWD_RT(8, 2, false);
+    else if (rt == 2) CGN_FWD_RTB(8, 2);
     else if (H <= 256) CGN_FWD_RTX(2, 4);
     else if (H <= 512) CGN_FWD_RTX(4, 4);
-    else CGN_FWD_RT(8, 4, false);
+    else CGN_FWD_RTB(8, 4);
+#undef CGN_FWD_RTB
 #undef CGN_FWD_RT
 #undef CGN_FWD_RTX
     CGN_LAUNCH_CHECK();
@@ -1732,16 +1750,18 @@ extern "C" int cgn_lstm_seq_bwd_persistent_f32(void* stream, const cgn_lstm_bwd_
 #define CGN_BWD_K(CPW) do { if (x6) hipLaunchKernelGGL((lstm_persist_bwd_kernel<CPW, true>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky); \
                             else hipLaunchKernelGGL((lstm_persist_bwd_kernel<CPW, false>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky); } while (0)
 #define CGN_BWD_RT(CPW, RT, X) hipLaunchKernelGGL((lstm_persist_bwd_rt_kernel<CPW, RT, X>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky)
-#define CGN_BWD_RTX(CPW, RT) do { if (x6) CGN_BWD_RT(CPW, RT, true); else CGN_BWD_RT(CPW, RT, false); } while (0)
+#define CGN_BWD_RTX(CPW, RT) do { if (x6) CGN_BWD_RT(CPW, RT, 3); else CGN_BWD_RT(CPW, RT, 0); } while (0)
+#define CGN_BWD_RTB(CPW, RT) do { if (g_lstm_operand_mode == 1) CGN_BWD_RT(CPW, RT, 2); else CGN_BWD_RT(CPW, RT, 0); } while (0)
     if (rt == 1 && H <= 256) CGN_BWD_K(8);
     else if (rt == 1 && H <= 512) CGN_BWD_K(16);
-    else if (rt == 1) CGN_BWD_RT(32, 1, false);
+    else if (rt == 1) CGN_BWD_RTB(32, 1);
     else if (rt == 2 && H <= 256) CGN_BWD_RTX(8, 2);
     else if (rt == 2 && H <= 512) CGN_BWD_RTX(16, 2);
-    else if (rt == 2) CGN_BWD_RT(32, 2, false);
+    else if (rt == 2) CGN_BWD_RTB(32, 2);
     else if (H <= 256) CGN_BWD_RTX(8, 4);
     else if (H <= 512) CGN_BWD_RTX(16, 4);
-    else CGN_BWD_RT(32, 4, false);
+    else CGN_BWD_RTB(32, 4);
+#undef CGN_BWD_RTB
 #undef CGN_BWD_K
 #undef CGN_BWD_RT
 #undef CGN_BWD_RTX
@@ -1809,5 +1829,11 @@ extern "C" int cgn_lstm2_bwd_persistent_f32(void* stream, const cgn_lstm2_bwd* d
     else if (lstm_x6_bwd()) hipLaunchKernelGGL((lstm2_persist_bwd_kernel<16, true>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky);
     else hipLaunchKernelGGL((lstm2_persist_bwd_kernel<16, false>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky);
     CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}
+
+extern "C" int cgn_lstm_set_operand_mode(int32_t mode) {
+    CGN_CHECK_ARG(mode == 0 || mode == 1);
+    g_lstm_operand_mode = mode;
     return CGN_OK;
 }

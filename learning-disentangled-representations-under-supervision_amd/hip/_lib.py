@@ -114,6 +114,7 @@ PROTOTYPES = {
     "cgn_softmax_nll_fwd_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_i32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "cgn_softmax_nll_fwd_bf16": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_i32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "cgn_log_softmax_rows_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i32, c_i64, c_i32, c_ptr, c_i64]),
+    "cgn_lstm_set_operand_mode": (c_i32, [c_i32]),
     "cgn_lstm_seq_fwd_f32": (c_i32, [c_ptr, C.POINTER(LstmFwdSeq), c_i32, c_i32, c_i32, c_i32]),
     "cgn_lstm_seq_bwd_f32": (c_i32, [c_ptr, C.POINTER(LstmBwdSeq), c_i32, c_i32, c_i32, c_i32]),
     "cgn_lstm_persistent_query": (c_i32, [c_i32, c_i32, c_i32, c_i32, C.POINTER(c_i64)]),

@@ -48,6 +48,20 @@ def _compute_code(compute):
 BF16_STORAGE = os.environ.get("CGN_BF16_STORAGE", "1") != "0"
 
 
+# bf16 mode: the row-tiled recurrences at H > 512 take two-term bf16 operands (cgn_lstm_set_operand_mode);
+# CGN_LSTM_BF16_RT=0 keeps them on the fp32 MFMA (A/B switch)
+LSTM_BF16_RT = os.environ.get("CGN_LSTM_BF16_RT", "1") != "0"
+
+
+def _sync_lstm_operand_mode():
+    try:
+        lib = _lib.load()
+    except RuntimeError:
+        return  # (no library: every op raises on its own)
+    _lib.check(lib.cgn_lstm_set_operand_mode(1 if (COMPUTE == _lib.COMPUTE_BF16 and LSTM_BF16_RT) else 0),
+               "cgn_lstm_set_operand_mode")
+
+
 def set_compute(mode):
     """'f32' | 'bf16'; returns the previous mode."""
     global COMPUTE
@@ -55,6 +69,7 @@ def set_compute(mode):
         raise ValueError("compute mode must be 'f32' or 'bf16'")
     prev = "bf16" if COMPUTE == _lib.COMPUTE_BF16 else "f32"
     COMPUTE = _lib.COMPUTE_BF16 if mode == "bf16" else _lib.COMPUTE_F32
+    _sync_lstm_operand_mode()
     return prev
 
 
@@ -1188,3 +1203,7 @@ def conv_bwd_dx_dense(Ks, Cos, act, layout, W, dfeat, feat, arg, B, L, E, dx, se
     cptrs = (C.c_void_p * n)(*[t_.data_ptr() for t_ in dcols])
     Karr = (C.c_int32 * n)(*Ks)
     _call("cgn_conv_col2im_f32", dev, n, cptrs, Karr, B, L, E, _ptr(dx), sent_stride)
+
+
+if COMPUTE == _lib.COMPUTE_BF16:
+    _sync_lstm_operand_mode()

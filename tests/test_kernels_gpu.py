@@ -380,3 +380,47 @@ def test_conv_dx_dense_route_matches_sparse_kernel(dev, layout, act):
     a = dx_a.view(B, stride)[:, :L * E]
     b = dx_b.view(B, stride)[:, :L * E]
     assert rel(b, a.double().cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("B,T,H,bidir", [(64, 5, 1024, False), (256, 4, 1024, True), (200, 3, 1024, False),
+                                          (128, 6, 768, False)])
+def test_row_tiled_lstm_two_term_operands_in_the_bf16_mode(dev, B, T, H, bidir):
+    """The optional bf16 mode's recurrences at H > 512 (cgn_lstm_set_operand_mode(1)): h.W_hh^T and dgates.W_hh from
+    two-term bf16 splits of both operands (three partial products). Against the fp32-MFMA launch of the same inputs:
+    not the same bits (the other kernel ran), and within 1e-4 - a hundred times inside the mode's 1e-2 allowance; RT 1, 4,
+    2 and a ragged chunk count (H = 768)."""
+    engine, ops = _mods()
+    nseq = 2 if bidir else 1
+    assert ops.lstm_persistent_group(nseq, B, T, H, dev) > 0
+    g = torch.Generator().manual_seed(B + H + T)
+    xg = [torch.randn(B, T, 4 * H, generator=g).to(dev) for _ in range(nseq)]
+    whh = [(torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dev) for _ in range(nseq)]
+    dcs = [torch.randn(B, H, generator=g).to(dev) for _ in range(nseq)]
+    exts = [(torch.randn(B, T, H, generator=g).to(dev), T * H, H) for _ in range(nseq)]
+
+    def run():
+        seqs = []
+        for i in range(nseq):
+            s = engine.LstmSeq(B, T, H, dev, bool(i))
+            s.xg.copy_(xg[i])
+            s.set_initial()
+            seqs.append(s)
+        engine.lstm_run_fwd(seqs, whh)
+        dgs = engine.lstm_run_bwd(seqs, whh, exts, [None] * nseq, [d.clone() for d in dcs])
+        torch.cuda.synchronize()
+        assert ops.lstm_sticky_timeouts() == 0 and ops.lstm_counters_at_rest(dev)
+        return [s.hbuf.clone() for s in seqs], [s.cbuf.clone() for s in seqs], [d.clone() for d in dgs]
+
+    ref = run()
+    prev = ops.set_compute("bf16")
+    try:
+        got = run()
+    finally:
+        ops.set_compute(prev)
+    again = run()
+    for a, b in zip(sum(ref, []), sum(again, [])):
+        assert torch.equal(a, b)  # the mode is off again
+    for name, r_, g_ in zip(("h", "c", "dgates"), ref, got):
+        for a, b in zip(r_, g_):
+            assert not torch.equal(a, b), name
+            assert rel(b, a.double().cpu()) < 1e-4, name
