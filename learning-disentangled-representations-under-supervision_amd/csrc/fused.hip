@@ -501,13 +501,27 @@ __global__ __launch_bounds__(LS_NT) void softmax_nll_from_stats_kernel(const flo
     float v = 0.f;
     if (row < M) {
         const f32x2* st = reinterpret_cast<const f32x2*>(stats + (long)row * ld_stats * 2);
-        float m = -INFINITY;
-        for (int c = lane; c < chunks; c += 64) m = fmaxf(m, st[c][0]);
-        m = wave_max(m);
-        float s = 0.f;
-        for (int c = lane; c < chunks; c += 64) {
-            const f32x2 q = st[c];
-            s += q[1] * __expf(q[0] - m);
+        float m = -INFINITY, s = 0.f;
+        if (chunks <= 64 * 8) {  // one pass: the row's statistics in registers (all loads in flight at once)
+            f32x2 q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = lane + 64 * u;
+                q[u] = st[c < chunks ? c : 0];
+                if (c >= chunks) q[u][0] = -INFINITY, q[u][1] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m = fmaxf(m, q[u][0]);
+            m = wave_max(m);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += q[u][1] * __expf(q[u][0] - m);  // (exp(-inf) = 0 for the empty slots)
+        } else {
+            for (int c = lane; c < chunks; c += 64) m = fmaxf(m, st[c][0]);
+            m = wave_max(m);
+            for (int c = lane; c < chunks; c += 64) {
+                const f32x2 q = st[c];
+                s += q[1] * __expf(q[0] - m);
+            }
         }
         s = wave_sum(s);
         const float l = m + logf(s);

@@ -92,6 +92,8 @@ int plan_gemm(const cgn_gemm_desc* d, int* bt_out, int* splitk_out, int* kps_out
         // handful of tiles (e2mu/e2logvar, d[z,c], the text-CNN windows) are pure latency chains of K/BK dependent
         // steps on one CU each: split them hard, whatever their FLOP count.
         const bool few = tiles < 64;
+        // (X6 128-tile products with 64-96 tiles - the LSTM weight gradients, 2048 x 512 x 1344 - were tried with splits
+        // down to K = 256 / 128: the step got 1.5 % / 3.5 % slower, profiles/r03_x6_tiles.txt)
         const int min_k = few ? 128 : (bt == 128 ? 512 : 256);
         long want = tiles >= 512 ? 1 : (1024 + tiles - 1) / tiles;
         // tall-K on the 64-tile (the soft embedding, 105 tiles x K = 20000): ~5 blocks per CU measured better than 4

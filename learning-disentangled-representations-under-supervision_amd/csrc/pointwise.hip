@@ -252,6 +252,53 @@ __global__ __launch_bounds__(PW_NT) void adam_kernel(float* __restrict__ p, cons
     }
 }
 
+// The same update, four elements per thread and trip (16-byte loads / stores: 4 loads of 16 bytes in flight per thread
+// instead of 4 of 4 bytes); element by element the arithmetic is adam_kernel's, so the results are bit-identical. The
+// generator's arena (14.3 M parameters, 400 MB of traffic) is the step's largest HBM-bound kernel.
+__global__ __launch_bounds__(PW_NT) void adam_vec4_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v, long n, float lr,
+                                                          float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                          const int* __restrict__ dyn_step, float grad_scale) {
+    if (dyn_step) {
+        const double t = (double)dyn_step[0];
+        bc1 = (float)(1.0 - pow((double)b1, t));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+    }
+    const float step_size = lr / bc1;
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * PW_NT + threadIdx.x; i < n4; i += (long)gridDim.x * PW_NT) {
+        const f32x4 g4 = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 m4 = reinterpret_cast<const f32x4*>(m)[i];
+        f32x4 v4 = reinterpret_cast<const f32x4*>(v)[i];
+        f32x4 p4 = reinterpret_cast<const f32x4*>(p)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gi = g4[e] * grad_scale;
+            const float mi = m4[e] + (gi - m4[e]) * (1.f - b1);
+            const float vi = b2 * v4[e] + (1.f - b2) * gi * gi;
+            m4[e] = mi;
+            v4[e] = vi;
+            const float denom = sqrtf(vi) / bc2_sqrt + eps;
+            p4[e] = p4[e] - step_size * (mi / denom);
+        }
+        reinterpret_cast<f32x4*>(m)[i] = m4;
+        reinterpret_cast<f32x4*>(v)[i] = v4;
+        reinterpret_cast<f32x4*>(p)[i] = p4;
+    }
+    if (blockIdx.x == 0) {  // n % 4 leftover elements
+        const long i = n4 * 4 + threadIdx.x;
+        if (i < n) {
+            const float gi = g[i] * grad_scale;
+            const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+            const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+            m[i] = mi;
+            v[i] = vi;
+            const float denom = sqrtf(vi) / bc2_sqrt + eps;
+            p[i] = p[i] - step_size * (mi / denom);
+        }
+    }
+}
+
 __global__ void incr_kernel(int* counter) { counter[0] += 1; }
 
 // ---- 2-class discriminator head: fc1 + CE / entropy losses and their gradient wrt the logits ---------------------
@@ -592,8 +639,13 @@ extern "C" int cgn_adam_f32(void* stream, float* p, const float* g, float* m, fl
     // count (graph replay) the kernel forms them itself, also in double
     const double bc1 = dyn_step ? 0.0 : 1.0 - pow((double)beta1, (double)step);
     const double bc2 = dyn_step ? 0.0 : 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(adam_kernel, dim3(pw_blocks(n, PW_NT, 8192)), dim3(PW_NT), 0, S_(stream), p, g, m, v, (long)n, lr,
-                       beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), dyn_step, grad_scale);
+    const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0) && n >= 4;
+    if (vec)
+        hipLaunchKernelGGL(adam_vec4_kernel, dim3(pw_blocks(n / 4, PW_NT, 8192)), dim3(PW_NT), 0, S_(stream), p, g, m, v,
+                           (long)n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), dyn_step, grad_scale);
+    else
+        hipLaunchKernelGGL(adam_kernel, dim3(pw_blocks(n, PW_NT, 8192)), dim3(PW_NT), 0, S_(stream), p, g, m, v, (long)n,
+                           lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), dyn_step, grad_scale);
     CGN_LAUNCH_CHECK();
     return CGN_OK;
 }

@@ -303,18 +303,22 @@ def test_reparam_kld_and_adam(dev):
     ops.reparam_kld_bwd(md, eps.float().to(dev), gz.float().to(dev), kc / B, dm)
     assert rel(dm, mulv.grad) < TOL
 
-    # Adam: three steps against torch.optim.Adam (fp32 on CPU)
-    n = 1000
-    p = torch.nn.Parameter(rnd(n, seed=40))
-    opt = torch.optim.Adam([p], 5e-5)
-    pd = p.detach().clone().to(dev)
-    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
-    for step in range(1, 4):
-        g = rnd(n, seed=40 + step)
-        p.grad = g.clone()
-        opt.step()
-        ops.adam(pd, g.to(dev), m, v, 5e-5, step)
-        assert (pd.cpu() - p.detach()).abs().max().item() < 1e-7
+    # Adam: three steps against torch.optim.Adam (fp32 on CPU): the 16-byte form (aligned arenas), its n % 4 tail, and
+    # the scalar form (an unaligned view)
+    for n, off in ((1000, 0), (1003, 0), (1001, 1), (3, 0)):
+        p = torch.nn.Parameter(rnd(n, seed=40))
+        opt = torch.optim.Adam([p], 5e-5)
+        pd = torch.zeros(n + off + 8, device=dev)[off:off + n]
+        pd.copy_(p.detach())
+        m, v = torch.zeros(n + off + 8, device=dev)[off:off + n], torch.zeros(n + off + 8, device=dev)[off:off + n]
+        for step in range(1, 4):
+            g = rnd(n, seed=40 + step)
+            p.grad = g.clone()
+            opt.step()
+            gd = torch.zeros(n + off + 8, device=dev)[off:off + n]
+            gd.copy_(g)
+            ops.adam(pd, gd, m, v, 5e-5, step)
+            assert (pd.cpu() - p.detach()).abs().max().item() < 1e-7, (n, off)
 
 
 def test_small_kernels(dev):
