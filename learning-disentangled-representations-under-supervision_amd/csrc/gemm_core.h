@@ -717,9 +717,18 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
             // fragment slot alternates with the step. A wave issues in order, so its own staging work of the next tile
             // (the three-way split: ~100 VALU instructions, 12 LDS writes, 4 global loads) is INTERLEAVED with the first
             // five terms' MFMAs (7 issue slots under each 32-cycle MFMA): two resident blocks that run in lock step - both
-            // splitting, then both multiplying - halve the matrix pipe's duty (measured: 0.43). The last term's MFMAs
-            // sit behind the barrier and cover the round trip of the next tile's fragment reads.
-            constexpr int QA = 5;
+            // splitting, then both multiplying - halve the matrix pipe's duty (measured: 0.43). QA = terms issued in front
+            // of the barrier, the rest behind it (covering the round trip of the next tile's fragment reads); swept with
+            // the VALU count per slot in the step (tools/r03_x6_sched.sh, profiles/r03_x6_sched_variants.txt): all six
+            // terms in front with five VALU per slot is best by 0.3-0.5 %, eight per slot or four terms in front lose 1 %
+            // - the other resident block covers the reads.
+#ifndef CGN_X6_QA
+#define CGN_X6_QA 6
+#endif
+#ifndef CGN_X6_VALU_PER_SLOT
+#define CGN_X6_VALU_PER_SLOT 5
+#endif
+            constexpr int QA = CGN_X6_QA;  // (tuning probes: tools/r03_x6_sched.sh builds variants with -D)
             la.template store<MASK>(st, An, k1 / KA, kend / KA, a_scale);
             lb.template store<MASK>(st, An + OPI, k1, kend, 0.f);
             la.load(st, p.A, p.ak, (k1 + S * BK) / KA, kbeg / KA, kend / KA);
@@ -728,7 +737,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int split, 
 #pragma unroll
             for (int g = 0; g < QA * TW * TW; ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // VALU of the split
+                __builtin_amdgcn_sched_group_barrier(0x002, CGN_X6_VALU_PER_SLOT, 0);  // VALU of the split
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // an LDS write
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // a global load
             }
