@@ -104,6 +104,8 @@ def host_cpu_model():
 
 def gemm_symbol(sym):
     """Kernel symbol of a product from ops.GEMM_PROFILE's key (csrc/gemm_core.h gemm_kernel's template arguments)."""
+    if sym[0] == "bb":  # the bf16 x bf16 kernel (csrc/bb_gemm.hip): 256x256 tile with 8 waves, or 128x128 with 4
+        return "cgn_bb::bb_kernel<4, 2, 2, 4>" if sym[1] == 256 else "cgn_bb::bb_kernel<2, 2, 2, 2>"
     bt, a_kc, b_kc, vec, exp, smb, bf16 = sym
     b = lambda v: "true" if v else "false"  # noqa: E731
     # vec: bits 0/1 = 16-byte loads on A/B (the template's VEC), bits 2.. = fast K addressing mode (the template's FK)
@@ -117,7 +119,7 @@ def gemm_symbol(sym):
 
 
 def is_x6(sym):
-    return bool(sym[3] & 32)
+    return sym[0] != "bb" and bool(sym[3] & 32)
 
 
 def main():
@@ -352,10 +354,12 @@ def main():
                 name = gemm_symbol(sym).replace("cgn_gemm::", "")
                 m = re.match(r"gemm_(?:group_)?kernel<(\d+)", name)
                 bt = int(m.group(1)) if m else 64
+                if sym[0] == "bb":
+                    bt = sym[1]
                 x6 = args.compute == "f32" and is_x6(sym)
                 pk = X6_MFMA_PEAK_TFLOPS if x6 else peak
                 bf = args.compute == "bf16" or x6  # (the model's constants are fp32-MFMA measurements: no model column then)
-                bk = (16 if bt == 128 else 32) * (2 if args.compute == "bf16" else 1)
+                bk = 32 if sym[0] == "bb" else (16 if bt == 128 else 32) * (2 if args.compute == "bf16" else 1)
                 tm, tn = math.ceil(M / bt), math.ceil(N / bt)
                 tiles = tm * tn * max(sk, 1)
                 per_cu = tiles / cus

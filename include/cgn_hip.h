@@ -525,6 +525,48 @@ int cgn_mul_f32(void* stream, const float* a, const float* b, float* out, int64_
 /* out[0] = sum_i coef[i]*src[i][0], n <= 4 (loss totals of model/cgn.py:329,334,1151-1152); src, coef: host arrays. */
 int cgn_lincomb_f32(void* stream, int32_t n, const float* const* src, const float* coef, float* out);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * bf16 x bf16 products of the optional bf16 mode (BASELINE configs[3] is stated in bf16): the nn.Linear / nn.LSTM
+ * input products of model/generator.py:17-22,58-61 and model/encoder.py:17-21,40 and their backward products, with
+ * BOTH operands held as bf16 in memory. cgn_gemm_f32 with CGN_COMPUTE_BF16 rounds fp32 operands while it stages them
+ * (every tile of an operand is re-read and re-rounded by every block that needs it, 4 bytes per element); here an
+ * operand is rounded ONCE by cgn_cast_bf16_f32 (round to nearest even, the same rounding) and the product reads
+ * 2 bytes per element with 16-byte loads: 256x256 block tiles, 8 waves of 128x64, v_mfma_f32_32x32x16_bf16, fp32
+ * accumulation. Same result as the CGN_COMPUTE_BF16 product of the fp32 operands up to fp32 summation order.
+ *   C[m,n] = alpha * sum_k A[m*lda + k] * B[n*ldb + k] + beta * C[m,n] + bias0[n] + bias1[n]
+ * A [M][lda], B [N][ldb]: bf16, k-contiguous, 16-byte aligned, lda % 8 == ldb % 8 == 0, K % 8 == 0 (a caller with
+ * another K pads with zeros: cgn_cast_bf16_f32 does), each operand below 2 GB. C fp32, or bf16 when c_bf16 != 0
+ * (then beta == 0, ldc % 8 == 0, C 16-byte aligned, no split along K).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct cgn_gemm_bb_desc {
+    const void* A;
+    const void* B;
+    void* C;
+    const float* bias0; /* nullable, length N */
+    const float* bias1; /* nullable, length N */
+    float* workspace;   /* split-K slabs, 16-byte aligned: splitk * M * ceil4(N) floats; may be NULL (no split) */
+    int64_t workspace_bytes;
+    int64_t lda, ldb, ldc; /* elements */
+    int32_t M, N, K;
+    float alpha, beta;
+    int32_t c_bf16;
+    int32_t force_tile;   /* 0 = heuristic, 128 or 256 */
+    int32_t force_splitk; /* 0 = heuristic */
+} cgn_gemm_bb_desc;
+/* ev_start / ev_stop: nullable hipEvent_t recorded on `stream` directly around the product kernel (bench.py's per-kernel
+ * timing, as cgn_gemm_timed_f32); tile / splitk: nullable, receive the plan that ran. */
+int cgn_gemm_bb(void* stream, const cgn_gemm_bb_desc* desc /* host */, void* ev_start, void* ev_stop, int32_t* tile,
+                int32_t* splitk);
+/* 1 when cgn_gemm_bb takes the shape (M, N >= 128, K >= 64: below that the casts cost more than they save) */
+int cgn_gemm_bb_wants(int32_t M, int32_t N, int32_t K);
+/* dst = bf16(src), round to nearest even. src: fp32, n_rows rows addressed by the two-level axis `rows` (as cgn_gemm_desc
+ * axes: plain matrices, [B,T+1,H] history buffers), n_cols columns of unit stride.
+ *   transpose == 0: dst[r * ld_dst + c], columns n_cols .. ld_dst-1 of every row written as zeros
+ *   transpose != 0: dst[c * ld_dst + r], columns n_rows .. ld_dst-1 of every row written as zeros
+ * ld_dst % 8 == 0 and >= the row length, dst 16-byte aligned. */
+int cgn_cast_bf16_f32(void* stream, const float* src, cgn_axis rows, int32_t n_rows, int32_t n_cols, void* dst,
+                      int64_t ld_dst, int32_t transpose);
+
 #ifdef __cplusplus
 }
 #endif

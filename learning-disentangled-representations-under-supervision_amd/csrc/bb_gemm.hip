@@ -1,0 +1,515 @@
+// bf16 x bf16 -> fp32 | bf16 products for gfx950 (cgn_gemm_bb, cgn_cast_bf16_f32; include/cgn_hip.h): the optional bf16
+// mode's nn.Linear / LSTM input products with both operands HELD in bf16.
+//
+// Why its own kernel: with bf16 operands the 128x128 tile of gemm_core.h is paced by LDS traffic, not by the matrix
+// pipe (per 16 k a block reads 16 KB of fragments and writes 8 KB for 128 MFMA cycles per SIMD), and converting fp32
+// operands at staging costs 4 bytes per element from L2 plus a cvt per pair, in every block that touches the tile.
+// Here:
+//   * block tile 256x256, 8 waves in a 2x4 grid, each wave 128x64 = 4x2 accumulators of 32x32 (128 accumulator
+//     registers): 6 fragment reads per 8 MFMAs, 48 KB of LDS reads + 16 KB of writes per 512 MFMA cycles per SIMD;
+//     a 128x128 variant (4 waves of 64x64, up to 3 blocks per CU) for products with few tiles;
+//   * operands are bf16 in memory, k-contiguous: a thread's 16-byte global load IS 8 consecutive k of one row and goes
+//     to LDS as one ds_write_b128, nothing is converted in the loop;
+//   * LDS image per operand and stage: [rows][32 k] bf16 = 64-byte rows WITHOUT padding, the 16-byte chunk c of row r
+//     stored at chunk position c ^ ((r >> 2) & 3): the staging writes (4 consecutive rows x 4 chunks per 16 lanes) and
+//     the fragment reads (16 consecutive rows, one chunk) both touch every bank once;
+//   * THREE LDS stages, K step 32, one barrier per step: while a step multiplies tile u, tile u+2 is written and the
+//     first fragments of tile u+1 (complete since the previous barrier) are read BEFORE the barrier, so no wave waits
+//     for an LDS round trip with an empty matrix pipe; global loads run two more steps ahead in registers;
+//   * buffer loads with a fixed per-lane offset and a scalar k offset; k chunks past the end of the K range and tiles
+//     past the last one are loads from an out-of-range offset (return 0): no masks, no branches in the loop;
+//   * blocks of one XCD (blockIdx % 8) walk 8-tile-tall column groups: an XCD's 32 resident blocks share 8 + 4 operand
+//     panels through its L2;
+//   * few-tile / tall-K products are split along K into fp32 slabs and summed in fixed order (bitwise reproducible).
+#include "common.h"
+
+namespace cgn_bb {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+struct Params {
+    const void* A;
+    const void* B;
+    void* C;
+    const float* bias0;
+    const float* bias1;
+    float* ws;
+    long lda, ldb, ldc, ldw;
+    int M, N, K;
+    int kps, splitk;  // k per split (multiple of 32)
+    int tiles_m, tiles_n;
+    float alpha, beta;
+    int c16;
+    int c_vec;  // bf16 C: rows allow 16-byte stores
+    unsigned a_bytes, b_bytes;
+};
+
+constexpr int BK = 32;
+constexpr int ROWB = BK * 2;  // bytes per LDS row
+constexpr int NS = 3;         // LDS stages
+constexpr int OOB = (int)0x80000000;
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    bf16x2 v;
+    v[0] = (__bf16)a;
+    v[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+template <int WTM, int WTN, int WVM, int WVN>
+__global__ __launch_bounds__(64 * WVM * WVN) void bb_kernel(const Params p) {
+    constexpr int BM = WVM * WTM * 32, BN = WVN * WTN * 32, NTH = 64 * WVM * WVN;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int LA = BM * 4 / NTH, LB = BN * 4 / NTH;  // 16-byte chunks per thread and tile
+    constexpr int RSTEP = NTH / 4;                       // rows between a thread's chunks
+    static_assert(BM * 4 % NTH == 0 && BN * 4 % NTH == 0 && RSTEP % 16 == 0, "loader geometry");
+    static_assert(WTN == 2 && WTM % 2 == 0, "the staged bf16 epilogue flushes 64 rows x 64 columns per wave");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NS * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WVN, wn = wave % WVN;
+    const int fr = lane & 31, fk = lane >> 5;
+
+    // block -> tile: XCD x (= blockIdx % 8) owns a contiguous run of logical ids; logical ids walk groups of GM tile rows
+    int tm, tn;
+    {
+        const int nb = gridDim.x, per = nb >> 3, rem = nb & 7;
+        const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+        const int l = x * per + (x < rem ? x : rem) + q;
+        constexpr int GM = 8;
+        const int span = GM * p.tiles_n;
+        const int g = l / span, in = l - g * span;
+        const int first = g * GM;
+        const int gsz = p.tiles_m - first < GM ? p.tiles_m - first : GM;
+        tm = first + in % gsz;
+        tn = in / gsz;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int split = blockIdx.y;
+    const int kbeg = split * p.kps;
+    const int kend = p.K < kbeg + p.kps ? p.K : kbeg + p.kps;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
+    const int lc = tid & 3, lr = tid >> 2;
+    int voa[LA], vob[LB];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        int row = m0 + lr + i * RSTEP;
+        row = row < p.M ? row : p.M - 1;  // clamped: rows past the end are never stored
+        voa[i] = (int)((long)row * p.lda * 2) + lc * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        int row = n0 + lr + i * RSTEP;
+        row = row < p.N ? row : p.N - 1;
+        vob[i] = (int)((long)row * p.ldb * 2) + lc * 16;
+    }
+    const int lds_w = lr * ROWB + ((lc ^ ((lr >> 2) & 3)) << 4);  // (RSTEP % 16 == 0: the same swizzle for every chunk)
+
+    u32x4 ga[2][LA], gb[2][LB];
+    auto gload = [&](int R, int kt) {  // global loads of tile kt into register stage R
+        const int k0 = kbeg + kt * BK;
+        const bool ok = k0 + lc * 8 < kend;
+        const int so = __builtin_amdgcn_readfirstlane(k0) * 2;
+#pragma unroll
+        for (int i = 0; i < LA; ++i)
+            ga[R][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, ok ? voa[i] : OOB, so, 0));
+#pragma unroll
+        for (int i = 0; i < LB; ++i)
+            gb[R][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, ok ? vob[i] : OOB, so, 0));
+    };
+    auto lstore = [&](int R, int st) {  // register stage R -> LDS stage at byte offset st
+#pragma unroll
+        for (int i = 0; i < LA; ++i) *reinterpret_cast<u32x4*>(lds + st + lds_w + i * RSTEP * ROWB) = ga[R][i];
+#pragma unroll
+        for (int i = 0; i < LB; ++i) *reinterpret_cast<u32x4*>(lds + st + A_BYTES + lds_w + i * RSTEP * ROWB) = gb[R][i];
+    };
+
+    f32x16 acc[WTM][WTN];
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // lane's fragment offsets inside an operand image: row fr of its 32-row tile, chunk (2s + fk) of sub-step s
+    const int sw = (fr >> 2) & 3;
+    int fo[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) fo[s] = fr * ROWB + (((2 * s + fk) ^ sw) << 4);
+    const int a_base = wm * (WTM * 32) * ROWB, b_base = A_BYTES + wn * (WTN * 32) * ROWB;
+    bf16x8 fa[2][WTM], fb[2][WTN];
+    auto fread = [&](int s, int st) {
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+            fa[s][i] = *reinterpret_cast<const bf16x8*>(lds + st + a_base + fo[s] + i * 32 * ROWB);
+#pragma unroll
+        for (int j = 0; j < WTN; ++j)
+            fb[s][j] = *reinterpret_cast<const bf16x8*>(lds + st + b_base + fo[s] + j * 32 * ROWB);
+    };
+    auto mfma = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+    };
+
+    // prologue: tiles 0 and 1 into LDS stages 0 and 1, tiles 2 and 3 on their way in the two register stages
+    gload(0, 0);
+    gload(1, 1);
+    lstore(0, 0);
+    gload(0, 2);
+    lstore(1, STAGE);
+    gload(1, 3);
+    __syncthreads();
+    fread(0, 0);
+
+    // step u: multiplies tile u (stage cur); writes tile u+2 (register stage u & 1) into stage st; loads tile u+4
+    int cur = 0, nxt = STAGE, st = 2 * STAGE;
+    auto step = [&](int R, int kt) {
+        fread(1, cur);
+        lstore(R, st);
+        gload(R, kt + 4);
+        mfma(0);
+        fread(0, nxt);  // tile u+1: complete since the barrier that ended step u-1
+        mfma(1);
+        __syncthreads();
+        const int t = cur;
+        cur = nxt;
+        nxt = st;
+        st = t;
+    };
+    // (an odd tile count runs one more step on a tile of zeros: loads past kend return 0)
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(0, kt);
+        step(1, kt + 1);
+    }
+
+    const int row0 = m0 + wm * (WTM * 32), col0 = n0 + wn * (WTN * 32);
+    if (p.splitk > 1) {  // slab of this split: plain partial sums, the reduce kernel applies the epilogue
+        float* slab = p.ws + (long)split * p.M * p.ldw;
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (row < p.M) {
+#pragma unroll
+                    for (int j = 0; j < WTN; ++j) {
+                        const int col = col0 + j * 32 + fr;
+                        if (col < p.N) slab[(long)row * p.ldw + col] = acc[i][j][r];
+                    }
+                }
+            }
+        return;
+    }
+    float bias[WTN];
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) {
+        const int col = col0 + j * 32 + fr;
+        const int cc = col < p.N ? col : 0;
+        bias[j] = (p.bias0 ? p.bias0[cc] : 0.f) + (p.bias1 ? p.bias1[cc] : 0.f);
+    }
+    if (!p.c16) {
+        float* Cf = reinterpret_cast<float*>(p.C);
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (row < p.M) {
+#pragma unroll
+                    for (int j = 0; j < WTN; ++j) {
+                        const int col = col0 + j * 32 + fr;
+                        if (col < p.N) {
+                            float v = p.alpha * acc[i][j][r] + bias[j];
+                            if (p.beta != 0.f) v += p.beta * Cf[(long)row * p.ldc + col];
+                            Cf[(long)row * p.ldc + col] = v;
+                        }
+                    }
+                }
+            }
+        return;
+    }
+    // bf16 C: 64 rows x 64 columns of the wave at a time through LDS (free after the loop), out as 16-byte row stores
+    constexpr int RS = 72;  // staging row stride in elements (144 bytes)
+    static_assert((NTH / 64) * 64 * RS * 2 <= NS * STAGE, "staging images must fit the operand stages");
+    __syncthreads();  // every wave is done with the operand stages
+    unsigned short* stg = reinterpret_cast<unsigned short*>(lds) + wave * (64 * RS);
+    unsigned short* Ch = reinterpret_cast<unsigned short*>(p.C);
+#pragma unroll
+    for (int h = 0; h < WTM / 2; ++h) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    // rows r and r + 1 of one column: two 2-byte writes (lanes along the columns: conflict-free)
+                    const int rl = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    const unsigned w = pack2(p.alpha * acc[2 * h + ii][j][r] + bias[j],
+                                             p.alpha * acc[2 * h + ii][j][r + 1] + bias[j]);
+                    stg[rl * RS + j * 32 + fr] = (unsigned short)(w & 0xffffu);
+                    stg[(rl + 1) * RS + j * 32 + fr] = (unsigned short)(w >> 16);
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-local image: written by this wave's lanes only
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int rl = ps * 8 + (lane >> 3), cc = (lane & 7) * 8;
+            const int row = row0 + h * 64 + rl, col = col0 + cc;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(stg + rl * RS + cc);
+            if (row < p.M && col < p.N) {
+                if (p.c_vec && col + 8 <= p.N) {
+                    *reinterpret_cast<u32x4*>(Ch + (long)row * p.ldc + col) = v;
+                } else {
+                    const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (col + q < p.N) Ch[(long)row * p.ldc + col + q] = e[q];
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+// Sums the slabs in fixed order and applies the linear epilogue (fp32 C only).
+__global__ __launch_bounds__(256) void bb_reduce_kernel(const Params p) {
+    const long total = (long)p.M * p.ldw, nvec = total / 4;
+    float* Cf = reinterpret_cast<float*>(p.C);
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
+        const long idx = v * 4;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int z0 = 0; z0 < p.splitk; z0 += 4) {
+            f32x4 part[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int z = z0 + u < p.splitk ? z0 + u : p.splitk - 1;
+                part[u] = *reinterpret_cast<const f32x4*>(p.ws + (long)z * total + idx);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (z0 + u < p.splitk) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s[j] += part[u][j];
+                }
+        }
+        const int row = (int)(idx / p.ldw), col = (int)(idx % p.ldw);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (col + j < p.N) {
+                float o = p.alpha * s[j];
+                if (p.bias0) o += p.bias0[col + j];
+                if (p.bias1) o += p.bias1[col + j];
+                const long ci = (long)row * p.ldc + col + j;
+                if (p.beta != 0.f) o += p.beta * Cf[ci];
+                Cf[ci] = o;
+            }
+    }
+}
+
+// ---- casts ---------------------------------------------------------------------------------------------------------
+struct RowAxis {
+    long stride, gs;
+    int rpg;  // 0 = plain
+};
+__device__ __forceinline__ long row_off(const RowAxis& a, int r) {
+    if (a.rpg == 0) return (long)r * a.stride;
+    const int g = r / a.rpg;
+    return (long)g * a.gs + (long)(r - g * a.rpg) * a.stride;
+}
+
+// dst[r][c] = bf16(src[r][c]), 8 columns per thread; columns n_cols..ld_dst-1 zero
+__global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict__ src, RowAxis ax, int n_rows, int n_cols,
+                                                        unsigned short* __restrict__ dst, long ld_dst, int vec) {
+    const int cpr = (int)(ld_dst / 8);  // 8-column chunks per row
+    const long total = (long)n_rows * cpr;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(v / cpr), c = (int)(v - (long)r * cpr) * 8;
+        const float* s = src + row_off(ax, r) + c;
+        float x[8];
+        if (vec && c + 8 <= n_cols) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(s), hi = *reinterpret_cast<const f32x4*>(s + 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[q] = lo[q], x[4 + q] = hi[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = c + q < n_cols ? s[q] : 0.f;
+        }
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = pack2(x[2 * q], x[2 * q + 1]);
+        *reinterpret_cast<u32x4*>(dst + (long)r * ld_dst + c) = o;
+    }
+}
+
+// dst[c][r] = bf16(src[r][c]): 64 x 64 tiles through LDS; columns n_rows..ld_dst-1 of every dst row zero
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, RowAxis ax, int n_rows,
+                                                             int n_cols, unsigned short* __restrict__ dst, long ld_dst) {
+    __shared__ unsigned short t[64][66];  // [c][r]; 132-byte rows: the 2-byte transposing writes spread over the banks
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    // read: 16 lanes x 4 columns per row, 16 rows per pass
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int rl = ps * 16 + (tid >> 4), cl = (tid & 15) * 4;
+        const int r = r0 + rl;
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < n_rows) {
+            const float* s = src + row_off(ax, r) + c0 + cl;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (c0 + cl + q < n_cols) x[q] = s[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[cl + q][rl] = (unsigned short)(pack2(x[q], 0.f) & 0xffffu);
+    }
+    __syncthreads();
+    // write: 8 lanes x 8 rows(r) per dst row (c), 32 dst rows per pass
+    const long rpad = ld_dst;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int cl = ps * 32 + (tid >> 3), rl = (tid & 7) * 8;
+        const int c = c0 + cl;
+        if (c < n_cols && r0 + rl < rpad) {
+            unsigned w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = (unsigned)t[cl][rl + 2 * q] | ((unsigned)t[cl][rl + 2 * q + 1] << 16);
+            u32x4 o;
+            o[0] = w[0], o[1] = w[1], o[2] = w[2], o[3] = w[3];
+            *reinterpret_cast<u32x4*>(dst + (long)c * ld_dst + r0 + rl) = o;  // (rows past n_rows were read as zeros)
+        }
+    }
+}
+
+static inline bool plan(const cgn_gemm_bb_desc* d, int* bt_out, int* sk_out, int* kps_out) {
+    const int K = d->K;
+    auto tiles_of = [&](int bt) { return (long)cgn_cdiv(d->M, bt) * cgn_cdiv(d->N, bt); };
+    // share of the block slots of the last round that hold a block
+    auto fill = [&](long blocks, int slots) { return (double)blocks / ((double)cgn_cdiv(blocks, slots) * slots); };
+    // splits along K that the caller's workspace can hold and that keep at least 512 k each
+    const long slab = (long)d->M * ((d->N + 3) / 4 * 4) * 4;
+    auto can = [&](int s) {
+        return s == 1 || (!d->c_bf16 && d->workspace != nullptr && K / s >= 512 && slab * s <= d->workspace_bytes);
+    };
+    // the smallest split whose fill is within 8 % of the best one
+    auto best_split = [&](long t, int slots, double* f) {
+        double top = 0.0;
+        for (int s = 1; s <= 16; ++s)
+            if (can(s)) top = fill(t * s, slots) > top ? fill(t * s, slots) : top;
+        for (int s = 1; s <= 16; ++s)
+            if (can(s) && fill(t * s, slots) >= 0.92 * top) {
+                *f = fill(t * s, slots);
+                return s;
+            }
+        *f = fill(t, slots);
+        return 1;
+    };
+    int bt = d->force_tile, sk = d->force_splitk;
+    if (bt == 0) {  // the 256-tile when (split or not) it fills 0.7 of its rounds of 256 blocks
+        double f = 0.0;
+        best_split(tiles_of(256), 256, &f);
+        bt = (d->M >= 256 && d->N >= 256 && f >= 0.7) ? 256 : 128;
+    }
+    if (sk == 0) {
+        double f;
+        sk = best_split(tiles_of(bt), bt == 256 ? 256 : 768, &f);
+    }
+    if (sk > 1 && (d->c_bf16 || d->workspace == nullptr)) return false;
+    int kps = cgn_cdiv(cgn_cdiv(K, sk), BK) * BK;
+    sk = cgn_cdiv(K, kps);
+    if (sk > 1 && slab * sk > d->workspace_bytes) return false;
+    *bt_out = bt;
+    *sk_out = sk;
+    *kps_out = kps;
+    return true;
+}
+
+}  // namespace cgn_bb
+
+using namespace cgn_bb;
+
+extern "C" int cgn_gemm_bb_wants(int32_t M, int32_t N, int32_t K) { return (M >= 128 && N >= 128 && K >= 64) ? 1 : 0; }
+
+extern "C" int cgn_gemm_bb(void* stream, const cgn_gemm_bb_desc* d, void* ev_start, void* ev_stop, int32_t* tile,
+                           int32_t* splitk) {
+    CGN_CHECK_ARG(d != nullptr);
+    CGN_CHECK_ARG(d->M >= 0 && d->N >= 0 && d->K >= 0 && d->M < (1 << 30) && d->N < (1 << 30) && d->K < (1 << 30));
+    if (tile) *tile = 0;
+    if (splitk) *splitk = 0;
+    if (d->M == 0 || d->N == 0) return CGN_OK;
+    CGN_CHECK_ARG(d->A && d->B && d->C && d->K > 0 && d->K % 8 == 0);
+    CGN_CHECK_ARG(d->lda % 8 == 0 && d->ldb % 8 == 0 && d->lda >= d->K && d->ldb >= d->K && d->ldc >= d->N);
+    CGN_CHECK_ARG((uintptr_t)d->A % 16 == 0 && (uintptr_t)d->B % 16 == 0 && (uintptr_t)d->workspace % 16 == 0);
+    CGN_CHECK_ARG(d->force_tile == 0 || d->force_tile == 128 || d->force_tile == 256);
+    CGN_CHECK_ARG(d->force_splitk >= 0 && d->force_splitk <= 64);
+    if (d->c_bf16) CGN_CHECK_ARG(d->beta == 0.f && (uintptr_t)d->C % 2 == 0 && d->force_splitk <= 1);
+    else CGN_CHECK_ARG((uintptr_t)d->C % 4 == 0);
+    const long ea = ((long)(d->M - 1) * d->lda + d->K) * 2, eb = ((long)(d->N - 1) * d->ldb + d->K) * 2;
+    CGN_CHECK_ARG(ea < (1L << 31) - 64 && eb < (1L << 31) - 64);
+    int bt, sk, kps;
+    CGN_CHECK_ARG(plan(d, &bt, &sk, &kps));
+    Params p;
+    p.A = d->A; p.B = d->B; p.C = d->C;
+    p.bias0 = d->bias0; p.bias1 = d->bias1; p.ws = d->workspace;
+    p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldw = (d->N + 3) / 4 * 4;
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.kps = kps; p.splitk = sk;
+    p.tiles_m = cgn_cdiv(d->M, bt); p.tiles_n = cgn_cdiv(d->N, bt);
+    p.alpha = d->alpha; p.beta = d->beta;
+    p.c16 = d->c_bf16 ? 1 : 0;
+    p.c_vec = (d->c_bf16 && d->ldc % 8 == 0 && (uintptr_t)d->C % 16 == 0) ? 1 : 0;
+    p.a_bytes = (unsigned)ea; p.b_bytes = (unsigned)eb;
+    if (tile) *tile = bt;
+    if (splitk) *splitk = sk;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((long)p.tiles_m * p.tiles_n), (unsigned)sk);
+    if (ev_start && hipEventRecord((hipEvent_t)ev_start, s) != hipSuccess) return CGN_ERR_HIP_BASE + (int)hipGetLastError();
+    if (bt == 256)
+        hipLaunchKernelGGL((bb_kernel<4, 2, 2, 4>), grid, dim3(512), 0, s, p);
+    else
+        hipLaunchKernelGGL((bb_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p);
+    CGN_LAUNCH_CHECK();
+    if (ev_stop && hipEventRecord((hipEvent_t)ev_stop, s) != hipSuccess) return CGN_ERR_HIP_BASE + (int)hipGetLastError();
+    if (sk > 1) {
+        int blocks = cgn_cdiv((long)d->M * p.ldw / 4, 256);
+        blocks = blocks > 2048 ? 2048 : (blocks < 1 ? 1 : blocks);
+        hipLaunchKernelGGL(bb_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
+        CGN_LAUNCH_CHECK();
+    }
+    return CGN_OK;
+}
+
+extern "C" int cgn_cast_bf16_f32(void* stream, const float* src, cgn_axis rows, int32_t n_rows, int32_t n_cols, void* dst,
+                                 int64_t ld_dst, int32_t transpose) {
+    CGN_CHECK_ARG(n_rows >= 0 && n_cols >= 0);
+    if (n_rows == 0 || n_cols == 0) return CGN_OK;
+    CGN_CHECK_ARG(src && dst && ld_dst % 8 == 0 && (uintptr_t)dst % 16 == 0);
+    CGN_CHECK_ARG(rows.stride >= 0 && rows.rpg >= 0 && rows.gs >= 0);
+    CGN_CHECK_ARG(ld_dst >= (transpose ? n_rows : n_cols));
+    RowAxis ax;
+    ax.stride = rows.stride; ax.gs = rows.gs; ax.rpg = (int)rows.rpg;
+    hipStream_t s = (hipStream_t)stream;
+    if (!transpose) {
+        const int vec = ((uintptr_t)src % 16 == 0 && rows.stride % 4 == 0 && (rows.rpg == 0 || rows.gs % 4 == 0)) ? 1 : 0;
+        const long total = (long)n_rows * (ld_dst / 8);
+        int blocks = cgn_cdiv(total, 256);
+        blocks = blocks > 8192 ? 8192 : blocks;
+        hipLaunchKernelGGL(cast_rows_kernel, dim3(blocks), dim3(256), 0, s, src, ax, n_rows, n_cols,
+                           reinterpret_cast<unsigned short*>(dst), (long)ld_dst, vec);
+    } else {
+        // the row tiles cover the padded row count so that the padding columns of dst are written (as zeros)
+        const dim3 grid((unsigned)cgn_cdiv(ld_dst, 64), (unsigned)cgn_cdiv(n_cols, 64));
+        CGN_CHECK_ARG(grid.y < 65536);
+        hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, s, src, ax, n_rows, n_cols,
+                           reinterpret_cast<unsigned short*>(dst), (long)ld_dst);
+    }
+    CGN_LAUNCH_CHECK();
+    return CGN_OK;
+}

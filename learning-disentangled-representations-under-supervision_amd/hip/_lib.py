@@ -55,6 +55,17 @@ class GemmDesc(C.Structure):
     ]
 
 
+class GemmBBDesc(C.Structure):
+    _fields_ = [
+        ("A", c_ptr), ("B", c_ptr), ("C", c_ptr), ("bias0", c_ptr), ("bias1", c_ptr),
+        ("workspace", c_ptr), ("workspace_bytes", c_i64),
+        ("lda", c_i64), ("ldb", c_i64), ("ldc", c_i64),
+        ("M", c_i32), ("N", c_i32), ("K", c_i32),
+        ("alpha", c_f32), ("beta", c_f32),
+        ("c_bf16", c_i32), ("force_tile", c_i32), ("force_splitk", c_i32),
+    ]
+
+
 class LstmFwdSeq(C.Structure):
     _fields_ = [("xg", c_ptr), ("xg_extra", c_ptr), ("w_hh", c_ptr), ("hbuf", c_ptr), ("cbuf", c_ptr),
                 ("gates", c_ptr), ("reverse", c_i32), ("init_zero", c_i32)]
@@ -167,6 +178,9 @@ PROTOTYPES = {
     "cgn_fill_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_f32]),
     "cgn_mul_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64]),
     "cgn_lincomb_f32": (c_i32, [c_ptr, c_i32, C.POINTER(c_ptr), C.POINTER(c_f32), c_ptr]),
+    "cgn_gemm_bb": (c_i32, [c_ptr, C.POINTER(GemmBBDesc), c_ptr, c_ptr, C.POINTER(c_i32), C.POINTER(c_i32)]),
+    "cgn_gemm_bb_wants": (c_i32, [c_i32, c_i32, c_i32]),
+    "cgn_cast_bf16_f32": (c_i32, [c_ptr, c_ptr, Axis, c_i32, c_i32, c_ptr, c_i64, c_i32]),
 }
 
 _lib = None

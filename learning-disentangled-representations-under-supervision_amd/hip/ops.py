@@ -102,15 +102,16 @@ def _chk_i64(t, name):
         raise TypeError("%s must be a contiguous int64 CUDA(HIP) tensor" % name)
 
 
-def workspace(device):
+def workspace(device, nbytes=None):
     """Split-K / column-sum workspace, one per (device, stream): kernels launched on different streams may overlap, so
-    they must not share slabs. Allocated once per key (the C library never allocates)."""
+    they must not share slabs. Allocated once per key (the C library never allocates). nbytes: a second, larger set for
+    the bf16 x bf16 products (the fp32 planner's choices depend on its workspace's size and stay as they are)."""
     idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream, nbytes)
     ws = _workspaces.get(key)
     if ws is None:
         with torch.cuda.stream(torch.cuda.default_stream(idx)):  # owned by the default stream's pool, never freed
-            ws = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=torch.device("cuda", idx))
+            ws = torch.empty((nbytes or WORKSPACE_BYTES) // 4, dtype=torch.float32, device=torch.device("cuda", idx))
         _workspaces[key] = ws
     return ws
 
@@ -225,6 +226,10 @@ def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, 
     dev = out.device
     if a.device != dev or b.device != dev:
         raise ValueError("operands on different devices")
+    if (BB_GEMM and not _desc_only and a_exp is None and softmax_bwd is None and lse_stats is None and c_t is None
+            and not force_tile and not force_splitk and _compute_code(compute) == _lib.COMPUTE_BF16):
+        if _gemm_bb_route(a, b, out, M, N, K, a_m, a_k, b_k, b_n, alpha, beta, bias0, bias1):
+            return out
     d = GemmDesc()
     d.A, d.B, d.C = _ptr(a), _ptr(b), _ptr(out)
     for name, t in (("bias0", bias0), ("bias1", bias1)):
@@ -316,6 +321,108 @@ def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, 
     with torch.cuda.device(dev):
         _lib.check(lib.cgn_gemm_f32(_stream(), C.byref(d)), "cgn_gemm_f32")
     return out if lse_stats is None else (out, stats)
+
+
+# bf16 mode: products of plain / history-buffer operands with M, N >= 128 run the bf16 x bf16 kernel (csrc/bb_gemm.hip)
+# on operands rounded ONCE by a cast kernel (transposing where the operand is not k-contiguous); CGN_BB_GEMM=0 keeps
+# them on the kernels that round fp32 operands at LDS staging (A/B switch). Below BB_MIN_FLOP the casts do not pay.
+BB_GEMM = os.environ.get("CGN_BB_GEMM", "1") != "0"
+BB_WORKSPACE_BYTES = 384 << 20  # split-K slabs of the tall-K products at configs[3] shapes (dH1: 3 x 43 MB)
+BB_MIN_FLOP = float(os.environ.get("CGN_BB_MIN_FLOP", "2e10"))
+
+
+def pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def cast_bf16(src, rows, n_rows, n_cols, transpose=False):
+    """bf16 copy of the fp32 matrix whose n_rows rows sit at the two-level Axis `rows` of `src` (unit column stride):
+    [n_rows, pad8(n_cols)], or transposed [n_cols, pad8(n_rows)]; padding columns are zeros (cgn_cast_bf16_f32)."""
+    _chk_f32(src, "src")
+    shape = (n_cols, pad8(n_rows)) if transpose else (n_rows, pad8(n_cols))
+    dst = alloc(shape, src.device, torch.bfloat16)
+    _call("cgn_cast_bf16_f32", src.device, _ptr(src), rows, n_rows, n_cols, _ptr(dst), shape[1], 1 if transpose else 0)
+    return dst
+
+
+def gemm_bb(a16, b16, out, *, K=None, alpha=1.0, beta=0.0, bias0=None, bias1=None, force_tile=0, force_splitk=0):
+    """out[M,N] = alpha * a16 @ b16^T + beta*out + bias0 + bias1 with bfloat16 a16 [M, >=K], b16 [N, >=K] (unit k
+    stride, row strides % 8 == 0, K % 8 == 0) and a float32 or bfloat16 out (cgn_gemm_bb)."""
+    lib = _lib.load()
+    for t, name in ((a16, "a16"), (b16, "b16")):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 2
+                and t.stride(1) == 1):
+            raise TypeError("%s must be a 2-D bfloat16 CUDA(HIP) tensor with unit column stride" % name)
+    c16 = _chk_f32_or_bf16(out, "out")
+    K = a16.shape[1] if K is None else K
+    M, N = a16.shape[0], b16.shape[0]
+    if K > a16.shape[1] or K > b16.shape[1] or K % 8:
+        raise ValueError("K must be a multiple of 8 inside both operands' rows")
+    if out.dim() != 2 or out.shape[0] != M or out.shape[1] != N or out.stride(1) != 1:
+        raise ValueError("out must be [M,N] with unit column stride")
+    dev = out.device
+    d = _lib.GemmBBDesc()
+    d.A, d.B, d.C = _ptr(a16), _ptr(b16), _ptr(out)
+    for name, t in (("bias0", bias0), ("bias1", bias1)):
+        if t is not None:
+            _chk_f32(t, name)
+            if t.numel() != N or not t.is_contiguous():
+                raise ValueError("%s must be contiguous with N elements" % name)
+        setattr(d, name, _ptr(t))
+    ws = workspace(dev, BB_WORKSPACE_BYTES)
+    d.workspace, d.workspace_bytes = _ptr(ws), ws.numel() * 4
+    d.lda, d.ldb, d.ldc = a16.stride(0), b16.stride(0), out.stride(0)
+    d.M, d.N, d.K = M, N, K
+    d.alpha, d.beta = alpha, beta
+    d.c_bf16 = 1 if c16 else 0
+    d.force_tile, d.force_splitk = force_tile, force_splitk
+    prof = GEMM_PROFILE
+    tile, sk = C.c_int32(), C.c_int32()
+    with torch.cuda.device(dev):
+        if prof is not None and prof["variant"] in (None, ("bb",)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(), e1.record()
+            _lib.check(lib.cgn_gemm_bb(_stream(), C.byref(d), e0.cuda_event, e1.cuda_event, C.byref(tile), C.byref(sk)),
+                       "cgn_gemm_bb")
+            prof["records"].append((("bb", tile.value, c16), sk.value, M, N, K, e0, e1))
+        else:
+            _lib.check(lib.cgn_gemm_bb(_stream(), C.byref(d), None, None, C.byref(tile), C.byref(sk)), "cgn_gemm_bb")
+    return out
+
+
+def _bb_operand(t, row_ax, k_ax, rows, K, is16):
+    """The bf16 [rows, pad8(K)] k-contiguous form of a GEMM operand given by its row axis and K axis, or None when the
+    addressing is not one the cast kernels take."""
+    if is16:
+        return t if (k_ax.stride == 1 and k_ax.rpg == 0 and row_ax.rpg == 0 and t.dim() == 2) else None
+    if k_ax.stride == 1 and k_ax.rpg == 0:  # k-contiguous: rows along the row axis
+        return cast_bf16(t, row_ax, rows, K)
+    if row_ax.stride == 1 and row_ax.rpg == 0:  # row-contiguous: the source's rows are the K axis
+        return cast_bf16(t, k_ax, K, rows, transpose=True)
+    return None
+
+
+def _gemm_bb_route(a, b, out, M, N, K, a_m, a_k, b_k, b_n, alpha, beta, bias0, bias1):
+    lib = _lib.load()
+    if not lib.cgn_gemm_bb_wants(M, N, K) or 2.0 * M * N * K < BB_MIN_FLOP:
+        return False
+    a16, c16 = a.dtype == torch.bfloat16, out.dtype == torch.bfloat16
+    if c16 and (beta != 0.0 or out.stride(0) % 8 or out.data_ptr() % 16):
+        return False
+    # (a cast reads 4-byte elements through a 64-bit offset: any span; the product addresses each operand in 31 bits)
+    if max(M, N) * pad8(K) * 2 >= (1 << 31) - 64:
+        return False
+    if a16 and not (a_k.stride == 1 and a_k.rpg == 0 and a_m.rpg == 0 and a.dim() == 2 and K % 8 == 0
+                    and a_m.stride % 8 == 0 and a.data_ptr() % 16 == 0 and M * a_m.stride * 2 < (1 << 31) - 64):
+        return False
+    ok = lambda row_ax, k_ax: ((k_ax.stride == 1 and k_ax.rpg == 0) or (row_ax.stride == 1 and row_ax.rpg == 0))
+    if (not a16 and not ok(a_m, a_k)) or not ok(b_n, b_k):
+        return False
+    A = _bb_operand(a, a_m, a_k, M, K, a16)
+    B = _bb_operand(b, b_n, b_k, N, K, False)
+    Kp = pad8(K)
+    gemm_bb(A if a16 else A[:M], B[:N], out, K=Kp if not a16 else K, alpha=alpha, beta=beta, bias0=bias0, bias1=bias1)
+    return True
 
 
 def gemm_group(calls):

@@ -610,3 +610,134 @@ def test_gemm_x6_group(dev, kind):
             single = torch.empty_like(out)
             ops.gemm(a, b, single, compute="f32x6", **kw)
             assert torch.equal(single, out)
+
+
+# ---- the bf16 x bf16 kernel of the bf16 mode (cgn_gemm_bb, cgn_cast_bf16_f32; csrc/bb_gemm.hip) ----------------------
+def test_cast_bf16_plain_history_axis_transposed_and_unaligned(dev):
+    """The casts round to nearest even exactly as torch does, follow the two-level row axis of a [B, T+1, H] history
+    buffer, zero their padding columns, and take unaligned sources (scalar loads)."""
+    ops = _ops()
+    from ldrs_amd.hip._lib import Axis
+    g = torch.Generator().manual_seed(11)
+    src = torch.randn(37, 21, 52, generator=g).to(dev)
+    rows = src[:, :20].reshape(-1, 52)
+    ax = Axis(52, 20, 21 * 52)
+    d = ops.cast_bf16(src, ax, 37 * 20, 52)
+    assert d.shape == (740, 56) and torch.equal(d[:, :52], rows.bfloat16()) and bool((d[:, 52:] == 0).all())
+    dt = ops.cast_bf16(src, ax, 37 * 20, 52, transpose=True)
+    assert dt.shape == (52, 744) and torch.equal(dt[:, :740], rows.t().bfloat16()) and bool((dt[:, 740:] == 0).all())
+    m = torch.randn(301, 777, generator=g).to(dev)
+    v = m[:, 1:]
+    d = ops.cast_bf16(v, Axis(777, 0, 0), 301, 776)
+    assert torch.equal(d[:, :776], v.bfloat16())
+    dt = ops.cast_bf16(v, Axis(777, 0, 0), 301, 776, transpose=True)
+    assert torch.equal(dt[:, :301], v.t().bfloat16()) and bool((dt[:, 301:] == 0).all())
+    # values that sit half way between two bf16 numbers go to the even one; infinities and NaN survive
+    x = torch.tensor([[1.00390625, 1.01171875, -1.00390625, float("inf"), float("nan"), 0.0, -0.0, 3e38]], device=dev)
+    d = ops.cast_bf16(x, Axis(8, 0, 0), 1, 8)
+    ref = x.bfloat16()
+    assert torch.equal(d.view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("M,N,K,kw", [
+    (256, 256, 64, {}), (300, 520, 328, {}), (513, 257, 1000, dict(bias=True, beta=0.5, alpha=0.7)),
+    (1000, 300, 2048, dict(splitk=3)), (640, 900, 4096, dict(tile=256, splitk=4, bias=True, beta=1.0)),
+    (128, 128, 64, dict(tile=128)), (1344, 2048, 512, dict(tile=128)), (1344, 2048, 512, dict(tile=256)),
+    (260, 264, 8, dict(tile=256)), (130, 3000, 40, {}), (1, 1, 8, dict(tile=128)), (257, 129, 72, dict(tile=256)),
+])
+def test_gemm_bb_against_fp64(dev, M, N, K, kw):
+    """fp32 C: the fp64 product of the bf16 operands up to fp32 summation error (2e-6 of sum |a||b|), exact on small
+    integers; both tiles, K tails (K % 32 != 0), one-step products, edge tiles, split-K with bias / beta / alpha."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    ints = (M + N + K) % 2 == 0
+    a, b = _mk((M, K), g, ints).to(dev).bfloat16(), _mk((N, K), g, ints).to(dev).bfloat16()
+    c0 = _mk((M, N), g, ints).to(dev)
+    out = c0.clone()
+    bias = kw.get("bias", False)
+    b0 = _mk((N,), g, ints).to(dev) if bias else None
+    b1 = _mk((N,), g, ints).to(dev) if bias else None
+    alpha, beta = (kw.get("alpha", 1.0), kw.get("beta", 0.0)) if not ints else (1.0, float(int(kw.get("beta", 0.0))))
+    ops.gemm_bb(a, b, out, alpha=alpha, beta=beta, bias0=b0, bias1=b1, force_tile=kw.get("tile", 0),
+                force_splitk=kw.get("splitk", 0))
+    ref = alpha * (a.double() @ b.double().t())
+    if bias:
+        ref = ref + b0.double() + b1.double()
+    ref = ref + beta * c0.double()
+    if ints:
+        assert torch.equal(out.double(), ref)
+    else:
+        scale = a.double().abs() @ b.double().abs().t() + 1.0
+        assert ((out.double() - ref).abs() / scale).max().item() < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(200, 1000, 520, 128), (777, 1032, 512, 256), (300, 260, 96, 0), (256, 257, 64, 256)])
+def test_gemm_bb_bf16_result(dev, M, N, K, tile):
+    """bf16 C (the vocabulary projection's logits): the fp32 result rounded once, through the LDS-staged 16-byte row
+    stores and the scalar tail of rows whose length is not a multiple of 8."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    a, b = torch.randn(M, K, generator=g).to(dev).bfloat16(), torch.randn(N, K, generator=g).to(dev).bfloat16()
+    bias = torch.randn(N, generator=g).to(dev)
+    ld = (N + 7) // 8 * 8
+    for buf in (torch.zeros(M, ld, device=dev, dtype=torch.bfloat16), torch.zeros(M, N + 3, device=dev, dtype=torch.bfloat16)):
+        out = buf[:, :N]
+        ops.gemm_bb(a, b, out, bias0=bias, force_tile=tile)
+        ref32 = torch.empty(M, N, device=dev)
+        ops.gemm_bb(a, b, ref32, bias0=bias, force_tile=tile)
+        assert torch.equal(out, ref32.bfloat16())
+        assert bool((buf[:, N:] == 0).all())  # nothing written past the row's end
+
+
+def test_gemm_bb_refuses_what_it_cannot_read(dev):
+    ops = _ops()
+    a = torch.zeros(64, 72, device=dev, dtype=torch.bfloat16)
+    b = torch.zeros(64, 72, device=dev, dtype=torch.bfloat16)
+    out = torch.zeros(64, 64, device=dev)
+    with pytest.raises(ValueError):
+        ops.gemm_bb(a, b, out, K=60)  # K % 8
+    with pytest.raises(RuntimeError):
+        ops.gemm_bb(a[:, 1:65], b[:, :64], out, K=64)  # rows not 16-byte aligned
+    with pytest.raises(RuntimeError):
+        ops.gemm_bb(a, b, out.bfloat16(), K=64, beta=1.0)  # a bf16 result cannot be accumulated into
+    with pytest.raises(RuntimeError):
+        ops.gemm_bb(a, b, out, K=64, force_tile=64)
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt"])
+def test_bf16_mode_routes_large_products_through_the_bb_kernel(dev, layout, monkeypatch):
+    """ops.gemm in the bf16 mode: with CGN_BB_GEMM (default) a large plain product is cast once and multiplied by the
+    bf16 x bf16 kernel; the result equals the kernel that rounds at LDS staging up to fp32 summation order, for every
+    operand orientation, with bias and beta, and for a history-buffer A operand."""
+    ops = _ops()
+    from ldrs_amd.hip._lib import Axis
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 520, 392, 300
+    A, B = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g)
+    a = A.to(dev) if layout[0] == "n" else A.t().contiguous().to(dev).t()
+    b = B.to(dev) if layout[1] == "n" else B.t().contiguous().to(dev).t()
+    bias = torch.randn(N, generator=g).to(dev)
+    c0 = torch.randn(M, N, generator=g).to(dev)
+    monkeypatch.setattr(ops, "BB_MIN_FLOP", 0.0)
+    res = []
+    for bb in (False, True):
+        monkeypatch.setattr(ops, "BB_GEMM", bb)
+        before = len(ops.KEEP) if ops.KEEP is not None else None
+        out = c0.clone()
+        ops.gemm(a, b, out, bias0=bias, beta=0.5, compute="bf16")
+        res.append(out)
+    assert _rel(res[1], res[0].double().cpu()) < 2e-6
+    assert _rel(res[1], (_bf(A) @ _bf(B) + bias.double().cpu() + 0.5 * c0.double().cpu())) < 2e-6
+    if layout == "nt":  # A = the rows (b, t < T) of a [B, T+1, H] history buffer
+        Bn, T, H = 26, 20, K
+        hist = torch.randn(Bn, T + 1, H, generator=g).to(dev)
+        ax = Axis(H, T, (T + 1) * H)
+        outs = []
+        for bb in (False, True):
+            monkeypatch.setattr(ops, "BB_GEMM", bb)
+            out = torch.empty(Bn * T, N, device=dev)
+            ops.gemm(hist, b, out, M=Bn * T, K=K, a_m=ax, a_k=Axis(1, 0, 0), compute="bf16")
+            outs.append(out)
+        assert _rel(outs[1], outs[0].double().cpu()) < 2e-6
+        ref = _bf(hist[:, :T].reshape(-1, H).cpu()) @ _bf(B)
+        assert _rel(outs[1], ref) < 2e-6
