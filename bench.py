@@ -105,7 +105,9 @@ def host_cpu_model():
 def gemm_symbol(sym):
     """Kernel symbol of a product from ops.GEMM_PROFILE's key (csrc/gemm_core.h gemm_kernel's template arguments)."""
     if sym[0] == "bb":  # the bf16 x bf16 kernel (csrc/bb_gemm.hip): 256x256 tile with 8 waves, or 128x128 with 4
-        return "cgn_bb::bb_kernel<4, 2, 2, 4>" if sym[1] == 256 else "cgn_bb::bb_kernel<2, 2, 2, 2>"
+        b = lambda v: "true" if v else "false"  # noqa: E731
+        waves = {256: "4, 2, 2, 4", 192: "4, 2, 2, 2", 128: "2, 2, 2, 2"}[sym[1]]
+        return "cgn_bb::bb_kernel<%s, %s, %s>" % (waves, b(sym[3]), b(sym[4]))
     bt, a_kc, b_kc, vec, exp, smb, bf16 = sym
     b = lambda v: "true" if v else "false"  # noqa: E731
     # vec: bits 0/1 = 16-byte loads on A/B (the template's VEC), bits 2.. = fast K addressing mode (the template's FK)
@@ -355,7 +357,7 @@ def main():
                 m = re.match(r"gemm_(?:group_)?kernel<(\d+)", name)
                 bt = int(m.group(1)) if m else 64
                 if sym[0] == "bb":
-                    bt = sym[1]
+                    bt = 128 if sym[1] == 128 else 256  # (192 = the 256x128 tile: the table's tile columns assume 256^2)
                 x6 = args.compute == "f32" and is_x6(sym)
                 pk = X6_MFMA_PEAK_TFLOPS if x6 else peak
                 bf = args.compute == "bf16" or x6  # (the model's constants are fp32-MFMA measurements: no model column then)

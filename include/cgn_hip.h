@@ -550,8 +550,27 @@ typedef struct cgn_gemm_bb_desc {
     int32_t M, N, K;
     float alpha, beta;
     int32_t c_bf16;
-    int32_t force_tile;   /* 0 = heuristic, 128 or 256 */
+    int32_t force_tile;   /* 0 = heuristic; 256 = 256x256 block tile, 192 = 256x128, 128 = 128x128 */
     int32_t force_splitk; /* 0 = heuristic */
+    /* The two logits-sized products of model/cgn.py:1103-1108 with the logits HELD in bf16, as cgn_gemm_desc has them:
+     * a_transform CGN_ATRANS_EXP: A (bf16 logits) enters the product as exp(A * a_scale - a_row_param[m]) - the soft
+     *   embedding softmax(logits / tau) @ E with the probabilities formed as the tiles are staged;
+     * epilogue CGN_EPI_SOFTMAX_BWD (c_bf16 only, no split along K): with p = exp(ep_logits[m,n] * ep_inv_tau - ep_lse[m]),
+     *   C[m,n] = p * (acc - ep_rowdot[m]) * ep_inv_tau + ep_ce_scale * (p - (n == ep_target[m])); ep_logits is bf16
+     *   [M][ep_ld] and may alias C; c_t: nullable bf16 [N][ld_ct >= M], the transposed copy of C.
+     * dyn_scalars: nullable DEVICE {inv_tau, ce_scale}, overriding a_scale / ep_inv_tau and ep_ce_scale at run time. */
+    int32_t a_transform;
+    int32_t epilogue;
+    float a_scale, ep_inv_tau, ep_ce_scale;
+    const float* a_row_param;
+    const void* ep_logits;
+    const float* ep_lse;
+    const float* ep_rowdot;
+    const int64_t* ep_target;
+    int64_t ep_ld;
+    void* c_t;
+    int64_t ld_ct;
+    const float* dyn_scalars;
 } cgn_gemm_bb_desc;
 /* ev_start / ev_stop: nullable hipEvent_t recorded on `stream` directly around the product kernel (bench.py's per-kernel
  * timing, as cgn_gemm_timed_f32); tile / splitk: nullable, receive the plan that ran. */

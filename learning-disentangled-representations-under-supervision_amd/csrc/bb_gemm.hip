@@ -44,8 +44,22 @@ struct Params {
     int c16;
     int c_vec;  // bf16 C: rows allow 16-byte stores
     unsigned a_bytes, b_bytes;
+    // EXPA: A := exp(A * a_scale - a_row_param[m]); SMB: the fused softmax / CE backward epilogue (cgn_gemm_bb_desc)
+    const float* a_row_param;
+    const float* dyn;  // optional device scalars {inv_tau, ce_scale}: override a_scale / ep_inv_tau and ep_ce_scale
+    const void* ep_logits;
+    const float* ep_lse;
+    const float* ep_rowdot;
+    const int64_t* ep_target;
+    void* ct;
+    long ep_ld, ldct;
+    int ct_vec;
+    float a_scale, ep_inv_tau, ep_ce_scale;
 };
 
+#ifndef CGN_BB_SCHED
+#define CGN_BB_SCHED 1
+#endif
 constexpr int BK = 32;
 constexpr int ROWB = BK * 2;  // bytes per LDS row
 constexpr int NS = 3;         // LDS stages
@@ -58,15 +72,22 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-template <int WTM, int WTN, int WVM, int WVN>
-__global__ __launch_bounds__(64 * WVM * WVN) void bb_kernel(const Params p) {
+// EXPA: the A operand holds bf16 logits and the product takes A := exp(A * a_scale - a_row_param[m]) (the softmax
+// probabilities of the soft embedding, model/cgn.py:1103-1106), formed between the global load and the LDS write.
+// SMB: the fused softmax / CE backward epilogue over bf16 logits, in place, with the optional transposed copy.
+// Waves per SIMD the variants are built for (register budget 512 / waves): 256x256 = one block of 8 waves per CU;
+// 256x128 = two blocks of 4 waves (one block's epilogue runs beside the other's K loop); 128x128 = three blocks.
+template <int WTM, int WTN, int WVM, int WVN, bool EXPA = false, bool SMB = false>
+__global__ __launch_bounds__(64 * WVM * WVN, (WTM == 2 ? 3 : 2)) void bb_kernel(const Params p) {
     constexpr int BM = WVM * WTM * 32, BN = WVN * WTN * 32, NTH = 64 * WVM * WVN;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
     constexpr int LA = BM * 4 / NTH, LB = BN * 4 / NTH;  // 16-byte chunks per thread and tile
     constexpr int RSTEP = NTH / 4;                       // rows between a thread's chunks
     static_assert(BM * 4 % NTH == 0 && BN * 4 % NTH == 0 && RSTEP % 16 == 0, "loader geometry");
     static_assert(WTN == 2 && WTM % 2 == 0, "the staged bf16 epilogue flushes 64 rows x 64 columns per wave");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NS * STAGE];
+    // (the fused epilogue's wave-local images, 13312 bytes per wave, outgrow the three stages of the 256x256 tile)
+    constexpr int EPI_BYTES = SMB ? (NTH / 64) * (32 * 68 * 4 + 32 * 72 * 2) : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WVN, wn = wave % WVN;
@@ -110,10 +131,22 @@ __global__ __launch_bounds__(64 * WVM * WVN) void bb_kernel(const Params p) {
     }
     const int lds_w = lr * ROWB + ((lc ^ ((lr >> 2) & 3)) << 4);  // (RSTEP % 16 == 0: the same swizzle for every chunk)
 
+    float rp[EXPA ? LA : 1];  // EXPA: the row parameter (log-sum-exp) of this thread's rows
+    float ascale = 0.f;
+    if constexpr (EXPA) {
+        ascale = p.dyn ? p.dyn[0] : p.a_scale;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int row = m0 + lr + i * RSTEP;
+            rp[i] = p.a_row_param[row < p.M ? row : p.M - 1];
+        }
+    }
     u32x4 ga[2][LA], gb[2][LB];
+    bool oka[2] = {false, false};
     auto gload = [&](int R, int kt) {  // global loads of tile kt into register stage R
         const int k0 = kbeg + kt * BK;
         const bool ok = k0 + lc * 8 < kend;
+        oka[R] = ok;
         const int so = __builtin_amdgcn_readfirstlane(k0) * 2;
 #pragma unroll
         for (int i = 0; i < LA; ++i)
@@ -124,7 +157,18 @@ __global__ __launch_bounds__(64 * WVM * WVN) void bb_kernel(const Params p) {
     };
     auto lstore = [&](int R, int st) {  // register stage R -> LDS stage at byte offset st
 #pragma unroll
-        for (int i = 0; i < LA; ++i) *reinterpret_cast<u32x4*>(lds + st + lds_w + i * RSTEP * ROWB) = ga[R][i];
+        for (int i = 0; i < LA; ++i) {
+            u32x4 v = ga[R][i];
+            if constexpr (EXPA) {  // (chunks past the K range must stay zero: exp(0 - lse) is not)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float lo = __builtin_bit_cast(float, v[w] << 16), hi = __builtin_bit_cast(float, v[w] & 0xffff0000u);
+                    const unsigned e = pack2(__expf(lo * ascale - rp[i]), __expf(hi * ascale - rp[i]));
+                    v[w] = oka[R] ? e : 0u;
+                }
+            }
+            *reinterpret_cast<u32x4*>(lds + st + lds_w + i * RSTEP * ROWB) = v;
+        }
 #pragma unroll
         for (int i = 0; i < LB; ++i) *reinterpret_cast<u32x4*>(lds + st + A_BYTES + lds_w + i * RSTEP * ROWB) = gb[R][i];
     };
@@ -173,12 +217,41 @@ __global__ __launch_bounds__(64 * WVM * WVN) void bb_kernel(const Params p) {
     // step u: multiplies tile u (stage cur); writes tile u+2 (register stage u & 1) into stage st; loads tile u+4
     int cur = 0, nxt = STAGE, st = 2 * STAGE;
     auto step = [&](int R, int kt) {
+        // Two phases, fenced for the scheduler (left alone hipcc hoists all twelve fragment reads and the four writes
+        // to the top of the step and issues the two MFMAs of each accumulator back to back: every wave of the block then
+        // queues at the LDS behind the barrier while the matrix pipe idles - 0.59 matrix-pipe busy at 8192^3):
+        //   phase 1: MFMAs of sub-step 0, one per slot, with the reads of sub-step 1 and the writes of tile u+2
+        //   phase 2: MFMAs of sub-step 1, with the reads of tile u+1's sub-step 0 (complete since the barrier that ended
+        //            step u-1) and the global loads of tile u+4
+        constexpr int NM = WTM * WTN, NR = WTM + WTN, NL = LA + LB;
+        static_assert(NR <= NM && NL <= NM, "one LDS read, one LDS write / global load per MFMA slot");
         fread(1, cur);
         lstore(R, st);
-        gload(R, kt + 4);
         mfma(0);
-        fread(0, nxt);  // tile u+1: complete since the barrier that ended step u-1
+#if CGN_BB_SCHED
+#pragma unroll
+        for (int g = 0; g < NM; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (g < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (g < NL) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        gload(R, kt + 4);
+        fread(0, nxt);
         mfma(1);
+#if CGN_BB_SCHED
+#pragma unroll
+        for (int g = 0; g < NM; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (g < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (g < NL) {
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         __syncthreads();
         const int t = cur;
         cur = nxt;
@@ -207,6 +280,125 @@ __global__ __launch_bounds__(64 * WVM * WVN) void bb_kernel(const Params p) {
                     }
                 }
             }
+        return;
+    }
+    if constexpr (SMB) {
+        // Fused softmax / CE backward (model/cgn.py:1086-1108 backwards; host: bf16 C, no split): with
+        // pr = exp(logits * inv_tau - lse[m]), C = pr * (acc - rowdot[m]) * inv_tau + ce_scale * (pr - [n == target[m]]),
+        // written over the logits. 525 M elements at configs[3] shapes: the epilogue is instruction-bound, so the
+        // arithmetic runs on ROW CHUNKS, not in the accumulators' layout (one column x 4 rows per lane: 2-byte LDS
+        // traffic per element, ~40 instructions each, 1.2 ms). Per 32-row slab of the wave:
+        //   1. the accumulators go to a wave-local fp32 image [32][68] (4-byte writes, lanes along the columns);
+        //   2. a lane owns 8 consecutive columns of one row, four times: its logits are ONE 16-byte global load (issued a
+        //      slab ahead), its sums two ds_read_b128; the 8 results leave as one 16-byte store to C and one
+        //      ds_write_b128 into a bf16 image [32][72];
+        //   3. the transposed copy reads that image down the columns (8 two-byte reads per 16-byte store to ct).
+        constexpr int RSF = 68, RSR = 72, WAVE_BYTES = 32 * RSF * 4 + 32 * RSR * 2;
+        __syncthreads();  // every wave is done with the operand stages
+        float* facc = reinterpret_cast<float*>(lds + wave * WAVE_BYTES);
+        unsigned short* simg = reinterpret_cast<unsigned short*>(lds + wave * WAVE_BYTES + 32 * RSF * 4);
+        const float inv_tau = p.dyn ? p.dyn[0] : p.ep_inv_tau;
+        const float ce_scale = p.dyn ? p.dyn[1] : p.ep_ce_scale;
+        const unsigned short* lgp = reinterpret_cast<const unsigned short*>(p.ep_logits);
+        unsigned short* Ch = reinterpret_cast<unsigned short*>(p.C);
+        unsigned short* Ct = reinterpret_cast<unsigned short*>(p.ct);
+        const bool lvec = p.ep_ld % 8 == 0 && (reinterpret_cast<uintptr_t>(p.ep_logits) & 15) == 0;
+        const int crl = lane >> 3, ccc = (lane & 7) * 8;  // the lane's row (+ 8 ps) and first column of its chunks
+        u32x4 lq[4];
+        auto load_slab = [&](int i) {
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = row0 + i * 32 + ps * 8 + crl, col = col0 + ccc;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (row < p.M && col < p.N) {
+                    const unsigned short* src = lgp + (long)row * p.ep_ld + col;
+                    if (lvec && col + 8 <= p.N) {
+                        v = *reinterpret_cast<const u32x4*>(src);
+                    } else {
+                        unsigned short e[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) e[q] = col + q < p.N ? src[q] : (unsigned short)0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = (unsigned)e[2 * q] | ((unsigned)e[2 * q + 1] << 16);
+                    }
+                }
+                lq[ps] = v;
+            }
+        };
+        load_slab(0);
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) {
+#pragma unroll
+            for (int j = 0; j < WTN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) facc[((r & 3) + 8 * (r >> 2) + 4 * fk) * RSF + j * 32 + fr] = acc[i][j][r];
+            float lse_r[4], rd_r[4];
+            int tg_r[4];
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = row0 + i * 32 + ps * 8 + crl;
+                const int rc = row < p.M ? row : 0;
+                lse_r[ps] = p.ep_lse[rc];
+                rd_r[ps] = p.ep_rowdot[rc];
+                tg_r[ps] = (int)p.ep_target[rc];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-local images
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int rl = ps * 8 + crl;
+                const int row = row0 + i * 32 + rl, col = col0 + ccc;
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(facc + rl * RSF + ccc);
+                const f32x4 s1 = *reinterpret_cast<const f32x4*>(facc + rl * RSF + ccc + 4);
+                const int tl = tg_r[ps] - col;  // the target's position inside the chunk, if any
+                u32x4 o;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float l0 = __builtin_bit_cast(float, lq[ps][w] << 16);
+                    const float l1 = __builtin_bit_cast(float, lq[ps][w] & 0xffff0000u);
+                    const float p0 = __expf(l0 * inv_tau - lse_r[ps]), p1 = __expf(l1 * inv_tau - lse_r[ps]);
+                    const float a0 = w < 2 ? s0[2 * w] : s1[2 * w - 4], a1 = w < 2 ? s0[2 * w + 1] : s1[2 * w - 3];
+                    const float v0 = p0 * (a0 - rd_r[ps]) * inv_tau + ce_scale * (p0 - (tl == 2 * w ? 1.f : 0.f));
+                    const float v1 = p1 * (a1 - rd_r[ps]) * inv_tau + ce_scale * (p1 - (tl == 2 * w + 1 ? 1.f : 0.f));
+                    o[w] = pack2(v0, v1);
+                }
+                *reinterpret_cast<u32x4*>(simg + rl * RSR + ccc) = o;
+                // (this chunk's logits sit in this lane's registers: the in-place store cannot run ahead of a read)
+                if (row < p.M && col < p.N) {
+                    if (p.c_vec && col + 8 <= p.N) {
+                        *reinterpret_cast<u32x4*>(Ch + (long)row * p.ldc + col) = o;
+                    } else {
+                        const unsigned short* e = reinterpret_cast<const unsigned short*>(&o);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            if (col + q < p.N) Ch[(long)row * p.ldc + col + q] = e[q];
+                    }
+                }
+            }
+            if (i + 1 < WTM) load_slab(i + 1);
+            if (Ct) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int cl = ps * 16 + (lane >> 2), rr = (lane & 3) * 8;
+                    const int col = col0 + cl, row = row0 + i * 32 + rr;
+                    u32x4 o;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        o[w] = (unsigned)simg[(rr + 2 * w) * RSR + cl] | ((unsigned)simg[(rr + 2 * w + 1) * RSR + cl] << 16);
+                    if (col < p.N && row < p.M) {
+                        if (p.ct_vec && row + 8 <= p.M) {
+                            *reinterpret_cast<u32x4*>(Ct + (long)col * p.ldct + row) = o;
+                        } else {
+                            const unsigned short* e = reinterpret_cast<const unsigned short*>(&o);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q)
+                                if (row + q < p.M) Ct[(long)col * p.ldct + row + q] = e[q];
+                        }
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         return;
     }
     float bias[WTN];
@@ -349,86 +541,108 @@ __global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict_
     }
 }
 
-// dst[c][r] = bf16(src[r][c]): 64 x 64 tiles through LDS; columns n_rows..ld_dst-1 of every dst row zero
+// dst[c][r] = bf16(src[r][c]): 64 x 64 tiles through LDS; columns n_rows..ld_dst-1 of every dst row zero. A thread
+// reads two consecutive rows at four columns (16-byte loads where the source allows), packs the row PAIR of each column
+// into one word and writes it to the [c][r / 2] image (33-word rows: the 64 lanes of a write touch 64 banks); a dst row
+// then leaves as 16-byte stores of 8 rows each.
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, RowAxis ax, int n_rows,
-                                                             int n_cols, unsigned short* __restrict__ dst, long ld_dst) {
-    __shared__ unsigned short t[64][66];  // [c][r]; 132-byte rows: the 2-byte transposing writes spread over the banks
+                                                             int n_cols, unsigned short* __restrict__ dst, long ld_dst,
+                                                             int vec) {
+    __shared__ unsigned t[64][33];
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const int tid = threadIdx.x;
-    // read: 16 lanes x 4 columns per row, 16 rows per pass
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        const int rl = ps * 16 + (tid >> 4), cl = (tid & 15) * 4;
-        const int r = r0 + rl;
-        float x[4] = {0.f, 0.f, 0.f, 0.f};
-        if (r < n_rows) {
-            const float* s = src + row_off(ax, r) + c0 + cl;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (c0 + cl + q < n_cols) x[q] = s[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) t[cl + q][rl] = (unsigned short)(pack2(x[q], 0.f) & 0xffffu);
-    }
-    __syncthreads();
-    // write: 8 lanes x 8 rows(r) per dst row (c), 32 dst rows per pass
-    const long rpad = ld_dst;
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
-        const int cl = ps * 32 + (tid >> 3), rl = (tid & 7) * 8;
-        const int c = c0 + cl;
-        if (c < n_cols && r0 + rl < rpad) {
-            unsigned w[4];
+        const int rp = ps * 16 + (tid >> 4), cl = (tid & 15) * 4;  // row pair, first of 4 columns
+        float x[2][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) w[q] = (unsigned)t[cl][rl + 2 * q] | ((unsigned)t[cl][rl + 2 * q + 1] << 16);
+        for (int h = 0; h < 2; ++h) {
+            const int r = r0 + 2 * rp + h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[h][q] = 0.f;
+            if (r < n_rows) {
+                const float* sp = src + row_off(ax, r) + c0 + cl;
+                if (vec && c0 + cl + 4 <= n_cols) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(sp);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x[h][q] = v[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c0 + cl + q < n_cols) x[h][q] = sp[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[cl + q][rp] = pack2(x[0][q], x[1][q]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int cl = ps * 32 + (tid >> 3), j = tid & 7;  // dst row, chunk of 8 rows
+        const int c = c0 + cl;
+        if (c < n_cols && r0 + 8 * j < ld_dst) {
             u32x4 o;
-            o[0] = w[0], o[1] = w[1], o[2] = w[2], o[3] = w[3];
-            *reinterpret_cast<u32x4*>(dst + (long)c * ld_dst + r0 + rl) = o;  // (rows past n_rows were read as zeros)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = t[cl][4 * j + e];
+            *reinterpret_cast<u32x4*>(dst + (long)c * ld_dst + r0 + 8 * j) = o;  // (rows past n_rows were read as zeros)
         }
     }
 }
 
-static inline bool plan(const cgn_gemm_bb_desc* d, int* bt_out, int* sk_out, int* kps_out) {
+struct Tile {
+    int code, bm, bn, slots;  // slots: blocks resident on 256 CUs (registers and LDS of the variant)
+    double rate;              // steady-state rate relative to the 256x256 tile (measured at 4096^3 ... 8192^3)
+};
+// code = cgn_gemm_bb_desc.force_tile: 256 -> 256x256 (8 waves), 192 -> 256x128 (4 waves of 128x64), 128 -> 128x128
+constexpr Tile TILES[3] = {{256, 256, 256, 256, 1.0}, {192, 256, 128, 512, 0.93}, {128, 128, 128, 768, 0.80}};
+
+static inline bool plan(const cgn_gemm_bb_desc* d, bool smb, Tile* t_out, int* sk_out, int* kps_out) {
     const int K = d->K;
-    auto tiles_of = [&](int bt) { return (long)cgn_cdiv(d->M, bt) * cgn_cdiv(d->N, bt); };
     // share of the block slots of the last round that hold a block
     auto fill = [&](long blocks, int slots) { return (double)blocks / ((double)cgn_cdiv(blocks, slots) * slots); };
     // splits along K that the caller's workspace can hold and that keep at least 512 k each
     const long slab = (long)d->M * ((d->N + 3) / 4 * 4) * 4;
     auto can = [&](int s) {
+        if (d->force_splitk) return s == d->force_splitk;
         return s == 1 || (!d->c_bf16 && d->workspace != nullptr && K / s >= 512 && slab * s <= d->workspace_bytes);
     };
-    // the smallest split whose fill is within 8 % of the best one
-    auto best_split = [&](long t, int slots, double* f) {
-        double top = 0.0;
-        for (int s = 1; s <= 16; ++s)
-            if (can(s)) top = fill(t * s, slots) > top ? fill(t * s, slots) : top;
-        for (int s = 1; s <= 16; ++s)
-            if (can(s) && fill(t * s, slots) >= 0.92 * top) {
-                *f = fill(t * s, slots);
-                return s;
+    double best = -1.0;
+    for (const Tile& t : TILES) {
+        if (d->force_tile && d->force_tile != t.code) continue;
+        if (smb && t.code == 128) continue;  // (the fused epilogue is built for the 128x64 wave tile)
+        const long tiles = (long)cgn_cdiv(d->M, t.bm) * cgn_cdiv(d->N, t.bn);
+        const double pad = (double)d->M * d->N / ((double)tiles * t.bm * t.bn);
+        for (int s = 1; s <= 16; ++s) {
+            if (!can(s)) continue;
+            // a split costs a slab round trip per block and a reduce pass: worth it only for a clearly better fill
+            const double score = t.rate * pad * fill(tiles * s, t.slots) * (1.0 - 0.02 * (s - 1));
+            if (score > best + 1e-9) {
+                best = score;
+                *t_out = t;
+                *sk_out = s;
             }
-        *f = fill(t, slots);
-        return 1;
-    };
-    int bt = d->force_tile, sk = d->force_splitk;
-    if (bt == 0) {  // the 256-tile when (split or not) it fills 0.7 of its rounds of 256 blocks
-        double f = 0.0;
-        best_split(tiles_of(256), 256, &f);
-        bt = (d->M >= 256 && d->N >= 256 && f >= 0.7) ? 256 : 128;
+        }
     }
-    if (sk == 0) {
-        double f;
-        sk = best_split(tiles_of(bt), bt == 256 ? 256 : 768, &f);
-    }
+    if (best < 0.0) return false;
+    int sk = *sk_out;
     if (sk > 1 && (d->c_bf16 || d->workspace == nullptr)) return false;
-    int kps = cgn_cdiv(cgn_cdiv(K, sk), BK) * BK;
+    const int kps = cgn_cdiv(cgn_cdiv(K, sk), BK) * BK;
     sk = cgn_cdiv(K, kps);
     if (sk > 1 && slab * sk > d->workspace_bytes) return false;
-    *bt_out = bt;
     *sk_out = sk;
     *kps_out = kps;
     return true;
+}
+
+template <bool EXPA, bool SMB>
+static void launch(const Tile& t, dim3 grid, hipStream_t s, const Params& p) {
+    if (t.code == 256)
+        hipLaunchKernelGGL((bb_kernel<4, 2, 2, 4, EXPA, SMB>), grid, dim3(512), 0, s, p);
+    else if (t.code == 192)
+        hipLaunchKernelGGL((bb_kernel<4, 2, 2, 2, EXPA, SMB>), grid, dim3(256), 0, s, p);
+    else if constexpr (!SMB)
+        hipLaunchKernelGGL((bb_kernel<2, 2, 2, 2, EXPA, false>), grid, dim3(256), 0, s, p);
 }
 
 }  // namespace cgn_bb
@@ -447,34 +661,52 @@ extern "C" int cgn_gemm_bb(void* stream, const cgn_gemm_bb_desc* d, void* ev_sta
     CGN_CHECK_ARG(d->A && d->B && d->C && d->K > 0 && d->K % 8 == 0);
     CGN_CHECK_ARG(d->lda % 8 == 0 && d->ldb % 8 == 0 && d->lda >= d->K && d->ldb >= d->K && d->ldc >= d->N);
     CGN_CHECK_ARG((uintptr_t)d->A % 16 == 0 && (uintptr_t)d->B % 16 == 0 && (uintptr_t)d->workspace % 16 == 0);
-    CGN_CHECK_ARG(d->force_tile == 0 || d->force_tile == 128 || d->force_tile == 256);
+    CGN_CHECK_ARG(d->force_tile == 0 || d->force_tile == 128 || d->force_tile == 192 || d->force_tile == 256);
     CGN_CHECK_ARG(d->force_splitk >= 0 && d->force_splitk <= 64);
+    CGN_CHECK_ARG(d->a_transform == CGN_ATRANS_NONE || (d->a_transform == CGN_ATRANS_EXP && d->a_row_param));
+    CGN_CHECK_ARG(d->epilogue == CGN_EPI_LINEAR || d->epilogue == CGN_EPI_SOFTMAX_BWD);
+    const bool smb = d->epilogue == CGN_EPI_SOFTMAX_BWD, expa = d->a_transform == CGN_ATRANS_EXP;
+    if (smb) {
+        CGN_CHECK_ARG(d->c_bf16 && !expa && d->ep_logits && d->ep_lse && d->ep_rowdot && d->ep_target && d->ep_ld >= d->N);
+        CGN_CHECK_ARG(d->force_tile != 128 && (uintptr_t)d->ep_logits % 2 == 0 && (uintptr_t)d->c_t % 2 == 0);
+        CGN_CHECK_ARG(d->c_t == nullptr || d->ld_ct >= d->M);
+    } else {
+        CGN_CHECK_ARG(d->c_t == nullptr);
+    }
     if (d->c_bf16) CGN_CHECK_ARG(d->beta == 0.f && (uintptr_t)d->C % 2 == 0 && d->force_splitk <= 1);
     else CGN_CHECK_ARG((uintptr_t)d->C % 4 == 0);
     const long ea = ((long)(d->M - 1) * d->lda + d->K) * 2, eb = ((long)(d->N - 1) * d->ldb + d->K) * 2;
     CGN_CHECK_ARG(ea < (1L << 31) - 64 && eb < (1L << 31) - 64);
-    int bt, sk, kps;
-    CGN_CHECK_ARG(plan(d, &bt, &sk, &kps));
+    Tile t = TILES[0];
+    int sk, kps;
+    CGN_CHECK_ARG(plan(d, smb, &t, &sk, &kps));
     Params p;
     p.A = d->A; p.B = d->B; p.C = d->C;
     p.bias0 = d->bias0; p.bias1 = d->bias1; p.ws = d->workspace;
     p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldw = (d->N + 3) / 4 * 4;
     p.M = d->M; p.N = d->N; p.K = d->K;
     p.kps = kps; p.splitk = sk;
-    p.tiles_m = cgn_cdiv(d->M, bt); p.tiles_n = cgn_cdiv(d->N, bt);
+    p.tiles_m = cgn_cdiv(d->M, t.bm); p.tiles_n = cgn_cdiv(d->N, t.bn);
     p.alpha = d->alpha; p.beta = d->beta;
     p.c16 = d->c_bf16 ? 1 : 0;
     p.c_vec = (d->c_bf16 && d->ldc % 8 == 0 && (uintptr_t)d->C % 16 == 0) ? 1 : 0;
     p.a_bytes = (unsigned)ea; p.b_bytes = (unsigned)eb;
-    if (tile) *tile = bt;
+    p.a_row_param = d->a_row_param; p.dyn = d->dyn_scalars;
+    p.ep_logits = d->ep_logits; p.ep_lse = d->ep_lse; p.ep_rowdot = d->ep_rowdot; p.ep_target = d->ep_target;
+    p.ct = d->c_t; p.ep_ld = d->ep_ld; p.ldct = d->ld_ct;
+    p.ct_vec = (d->c_t && d->ld_ct % 8 == 0 && (uintptr_t)d->c_t % 16 == 0) ? 1 : 0;
+    p.a_scale = d->a_scale; p.ep_inv_tau = d->ep_inv_tau; p.ep_ce_scale = d->ep_ce_scale;
+    if (tile) *tile = t.code;
     if (splitk) *splitk = sk;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)((long)p.tiles_m * p.tiles_n), (unsigned)sk);
     if (ev_start && hipEventRecord((hipEvent_t)ev_start, s) != hipSuccess) return CGN_ERR_HIP_BASE + (int)hipGetLastError();
-    if (bt == 256)
-        hipLaunchKernelGGL((bb_kernel<4, 2, 2, 4>), grid, dim3(512), 0, s, p);
+    if (smb)
+        launch<false, true>(t, grid, s, p);
+    else if (expa)
+        launch<true, false>(t, grid, s, p);
     else
-        hipLaunchKernelGGL((bb_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p);
+        launch<false, false>(t, grid, s, p);
     CGN_LAUNCH_CHECK();
     if (ev_stop && hipEventRecord((hipEvent_t)ev_stop, s) != hipSuccess) return CGN_ERR_HIP_BASE + (int)hipGetLastError();
     if (sk > 1) {
@@ -507,8 +739,9 @@ extern "C" int cgn_cast_bf16_f32(void* stream, const float* src, cgn_axis rows, 
         // the row tiles cover the padded row count so that the padding columns of dst are written (as zeros)
         const dim3 grid((unsigned)cgn_cdiv(ld_dst, 64), (unsigned)cgn_cdiv(n_cols, 64));
         CGN_CHECK_ARG(grid.y < 65536);
+        const int vec = ((uintptr_t)src % 16 == 0 && rows.stride % 4 == 0 && (rows.rpg == 0 || rows.gs % 4 == 0)) ? 1 : 0;
         hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, s, src, ax, n_rows, n_cols,
-                           reinterpret_cast<unsigned short*>(dst), (long)ld_dst);
+                           reinterpret_cast<unsigned short*>(dst), (long)ld_dst, vec);
     }
     CGN_LAUNCH_CHECK();
     return CGN_OK;

@@ -63,6 +63,10 @@ class GemmBBDesc(C.Structure):
         ("M", c_i32), ("N", c_i32), ("K", c_i32),
         ("alpha", c_f32), ("beta", c_f32),
         ("c_bf16", c_i32), ("force_tile", c_i32), ("force_splitk", c_i32),
+        ("a_transform", c_i32), ("epilogue", c_i32),
+        ("a_scale", c_f32), ("ep_inv_tau", c_f32), ("ep_ce_scale", c_f32),
+        ("a_row_param", c_ptr), ("ep_logits", c_ptr), ("ep_lse", c_ptr), ("ep_rowdot", c_ptr), ("ep_target", c_ptr),
+        ("ep_ld", c_i64), ("c_t", c_ptr), ("ld_ct", c_i64), ("dyn_scalars", c_ptr),
     ]
 
 

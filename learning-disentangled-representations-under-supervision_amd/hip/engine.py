@@ -257,10 +257,11 @@ def lstm_param_grads(seq, dgates, x_operand, dW_ih, dW_hh, db_ih, db_hh, beta=0.
     B, T, H = seq.B, seq.T, seq.H
     dg2 = dgates.view(B * T, 4 * H)
     xt, xk = x_operand
-    if dW_ih is not None:
-        ops.gemm(dg2.t(), xt, dW_ih, N=dW_ih.shape[1], K=B * T, b_k=xk, b_n=LIN, beta=beta)
     hp, hk = seq.hprev_operand()
-    ops.gemm(dg2.t(), hp, dW_hh, N=H, K=B * T, b_k=hk, b_n=LIN, beta=beta)
+    with ops.bb_memo():  # (bf16 mode: the transposed bf16 copy of dG serves both products)
+        if dW_ih is not None:
+            ops.gemm(dg2.t(), xt, dW_ih, N=dW_ih.shape[1], K=B * T, b_k=xk, b_n=LIN, beta=beta)
+        ops.gemm(dg2.t(), hp, dW_hh, N=H, K=B * T, b_k=hk, b_n=LIN, beta=beta)
     ops.colsum(dg2, db_ih, beta=beta)
     if beta == 0.0:
         ops.copy2d(db_ih.view(1, -1), db_hh.view(1, -1))  # both biases enter the gates additively: same gradient

@@ -226,9 +226,9 @@ def gemm(a, b, out, *, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias0=None, 
     dev = out.device
     if a.device != dev or b.device != dev:
         raise ValueError("operands on different devices")
-    if (BB_GEMM and not _desc_only and a_exp is None and softmax_bwd is None and lse_stats is None and c_t is None
-            and not force_tile and not force_splitk and _compute_code(compute) == _lib.COMPUTE_BF16):
-        if _gemm_bb_route(a, b, out, M, N, K, a_m, a_k, b_k, b_n, alpha, beta, bias0, bias1):
+    if (BB_GEMM and not _desc_only and lse_stats is None and not force_tile and not force_splitk
+            and _compute_code(compute) == _lib.COMPUTE_BF16):
+        if _gemm_bb_route(a, b, out, M, N, K, a_m, a_k, b_k, b_n, alpha, beta, bias0, bias1, a_exp, softmax_bwd, c_t, dyn):
             return out
     d = GemmDesc()
     d.A, d.B, d.C = _ptr(a), _ptr(b), _ptr(out)
@@ -335,6 +335,22 @@ def pad8(n):
     return (n + 7) // 8 * 8
 
 
+# While a bb_memo() block is open, ops.gemm's bf16 copies of fp32 operands are kept and served again to later products
+# of the block that name the same operand (same base, axes, extents). The caller promises that the operands are not
+# written inside the block.
+_BB_MEMO = None
+
+
+@contextlib.contextmanager
+def bb_memo():
+    global _BB_MEMO
+    prev, _BB_MEMO = _BB_MEMO, ({} if _BB_MEMO is None else _BB_MEMO)
+    try:
+        yield
+    finally:
+        _BB_MEMO = prev
+
+
 def cast_bf16(src, rows, n_rows, n_cols, transpose=False):
     """bf16 copy of the fp32 matrix whose n_rows rows sit at the two-level Axis `rows` of `src` (unit column stride):
     [n_rows, pad8(n_cols)], or transposed [n_cols, pad8(n_rows)]; padding columns are zeros (cgn_cast_bf16_f32)."""
@@ -345,9 +361,12 @@ def cast_bf16(src, rows, n_rows, n_cols, transpose=False):
     return dst
 
 
-def gemm_bb(a16, b16, out, *, K=None, alpha=1.0, beta=0.0, bias0=None, bias1=None, force_tile=0, force_splitk=0):
+def gemm_bb(a16, b16, out, *, K=None, alpha=1.0, beta=0.0, bias0=None, bias1=None, force_tile=0, force_splitk=0,
+            a_exp=None, softmax_bwd=None, c_t=None, dyn=None):
     """out[M,N] = alpha * a16 @ b16^T + beta*out + bias0 + bias1 with bfloat16 a16 [M, >=K], b16 [N, >=K] (unit k
-    stride, row strides % 8 == 0, K % 8 == 0) and a float32 or bfloat16 out (cgn_gemm_bb)."""
+    stride, row strides % 8 == 0, K % 8 == 0) and a float32 or bfloat16 out (cgn_gemm_bb). force_tile: 256 | 192 (the
+    256x128 tile) | 128. a_exp=(scale, lse): a16 := exp(a16*scale - lse[m]); softmax_bwd=dict(logits (bfloat16), lse,
+    rowdot, target, inv_tau, ce_scale) with a bfloat16 out and the optional transposed copy c_t [N, >=M], as gemm()."""
     lib = _lib.load()
     for t, name in ((a16, "a16"), (b16, "b16")):
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 2
@@ -376,6 +395,32 @@ def gemm_bb(a16, b16, out, *, K=None, alpha=1.0, beta=0.0, bias0=None, bias1=Non
     d.alpha, d.beta = alpha, beta
     d.c_bf16 = 1 if c16 else 0
     d.force_tile, d.force_splitk = force_tile, force_splitk
+    d.a_transform, d.epilogue = _lib.ATRANS_NONE, _lib.EPI_LINEAR
+    if a_exp is not None:
+        scale, lse = a_exp
+        _chk_f32(lse, "lse")
+        if lse.numel() != M or not lse.is_contiguous():
+            raise ValueError("lse must have M elements")
+        d.a_transform, d.a_scale, d.a_row_param = _lib.ATRANS_EXP, scale, _ptr(lse)
+    if softmax_bwd is not None:
+        lg, lse, rd, tg = (softmax_bwd[k] for k in ("logits", "lse", "rowdot", "target"))
+        _chk_f32(lse, "lse"), _chk_f32(rd, "rowdot"), _chk_i64(tg, "target")
+        if not (c16 and lg.dtype == torch.bfloat16 and lg.is_cuda and lg.dim() == 2 and lg.shape[0] == M
+                and lg.shape[1] == N and lg.stride(1) == 1):
+            raise ValueError("softmax_bwd here takes bfloat16 logits [M,N] and a bfloat16 out")
+        if lse.numel() != M or rd.numel() != M or tg.numel() != M or not (lse.is_contiguous() and rd.is_contiguous()):
+            raise ValueError("softmax_bwd row vectors must have M elements")
+        d.epilogue = _lib.EPI_SOFTMAX_BWD
+        d.ep_logits, d.ep_lse, d.ep_rowdot, d.ep_target = _ptr(lg), _ptr(lse), _ptr(rd), _ptr(tg)
+        d.ep_ld = lg.stride(0)
+        d.ep_inv_tau, d.ep_ce_scale = softmax_bwd["inv_tau"], softmax_bwd["ce_scale"]
+    if c_t is not None:
+        if not (softmax_bwd is not None and isinstance(c_t, torch.Tensor) and c_t.is_cuda and c_t.dtype == torch.bfloat16
+                and c_t.dim() == 2 and c_t.shape[0] == N and c_t.shape[1] == M and c_t.stride(1) == 1
+                and c_t.device == dev):
+            raise ValueError("c_t must be a bfloat16 [N,M] matrix beside a bfloat16 softmax_bwd result")
+        d.c_t, d.ld_ct = _ptr(c_t), c_t.stride(0)
+    d.dyn_scalars = _ptr(dyn)
     prof = GEMM_PROFILE
     tile, sk = C.c_int32(), C.c_int32()
     with torch.cuda.device(dev):
@@ -384,7 +429,8 @@ def gemm_bb(a16, b16, out, *, K=None, alpha=1.0, beta=0.0, bias0=None, bias1=Non
             e0.record(), e1.record()
             _lib.check(lib.cgn_gemm_bb(_stream(), C.byref(d), e0.cuda_event, e1.cuda_event, C.byref(tile), C.byref(sk)),
                        "cgn_gemm_bb")
-            prof["records"].append((("bb", tile.value, c16), sk.value, M, N, K, e0, e1))
+            prof["records"].append((("bb", tile.value, c16, a_exp is not None, softmax_bwd is not None), sk.value,
+                                    M, N, K, e0, e1))
         else:
             _lib.check(lib.cgn_gemm_bb(_stream(), C.byref(d), None, None, C.byref(tile), C.byref(sk)), "cgn_gemm_bb")
     return out
@@ -395,18 +441,33 @@ def _bb_operand(t, row_ax, k_ax, rows, K, is16):
     addressing is not one the cast kernels take."""
     if is16:
         return t if (k_ax.stride == 1 and k_ax.rpg == 0 and row_ax.rpg == 0 and t.dim() == 2) else None
-    if k_ax.stride == 1 and k_ax.rpg == 0:  # k-contiguous: rows along the row axis
-        return cast_bf16(t, row_ax, rows, K)
-    if row_ax.stride == 1 and row_ax.rpg == 0:  # row-contiguous: the source's rows are the K axis
-        return cast_bf16(t, k_ax, K, rows, transpose=True)
-    return None
+    kc = k_ax.stride == 1 and k_ax.rpg == 0  # k-contiguous: rows along the row axis
+    if not kc and not (row_ax.stride == 1 and row_ax.rpg == 0):
+        return None
+    ax = row_ax if kc else k_ax  # (row-contiguous: the source's rows are the K axis, cast with a transpose)
+    key = (t.data_ptr(), ax.stride, ax.rpg, ax.gs, rows, K, kc)
+    if _BB_MEMO is not None and key in _BB_MEMO:
+        return _BB_MEMO[key]
+    r = cast_bf16(t, ax, rows, K) if kc else cast_bf16(t, ax, K, rows, transpose=True)
+    if _BB_MEMO is not None:
+        _BB_MEMO[key] = r
+    return r
 
 
-def _gemm_bb_route(a, b, out, M, N, K, a_m, a_k, b_k, b_n, alpha, beta, bias0, bias1):
+def _gemm_bb_route(a, b, out, M, N, K, a_m, a_k, b_k, b_n, alpha, beta, bias0, bias1, a_exp=None, softmax_bwd=None,
+                   c_t=None, dyn=None):
     lib = _lib.load()
-    if not lib.cgn_gemm_bb_wants(M, N, K) or 2.0 * M * N * K < BB_MIN_FLOP:
+    # (the two logits-sized products cast only their small operand: they pay from a fifth of the size on)
+    floor = BB_MIN_FLOP * (0.2 if (a_exp is not None or softmax_bwd is not None) else 1.0)
+    if not lib.cgn_gemm_bb_wants(M, N, K) or 2.0 * M * N * K < floor:
         return False
     a16, c16 = a.dtype == torch.bfloat16, out.dtype == torch.bfloat16
+    if a_exp is not None and not a16:  # (the exp loader reads bf16 logits: the bf16 storage of the mode)
+        return False
+    if softmax_bwd is not None and not (c16 and softmax_bwd["logits"].dtype == torch.bfloat16 and a_exp is None):
+        return False
+    if c_t is not None and softmax_bwd is None:
+        return False
     if c16 and (beta != 0.0 or out.stride(0) % 8 or out.data_ptr() % 16):
         return False
     # (a cast reads 4-byte elements through a 64-bit offset: any span; the product addresses each operand in 31 bits)
@@ -421,7 +482,8 @@ def _gemm_bb_route(a, b, out, M, N, K, a_m, a_k, b_k, b_n, alpha, beta, bias0, b
     A = _bb_operand(a, a_m, a_k, M, K, a16)
     B = _bb_operand(b, b_n, b_k, N, K, False)
     Kp = pad8(K)
-    gemm_bb(A if a16 else A[:M], B[:N], out, K=Kp if not a16 else K, alpha=alpha, beta=beta, bias0=bias0, bias1=bias1)
+    gemm_bb(A if a16 else A[:M], B[:N], out, K=Kp if not a16 else K, alpha=alpha, beta=beta, bias0=bias0, bias1=bias1,
+            a_exp=a_exp, softmax_bwd=softmax_bwd, c_t=c_t, dyn=dyn)
     return True
 
 

@@ -324,8 +324,9 @@ def test_gemm_bf16_storage_rejects_what_it_cannot_read(dev):
         ops.gemm(a, b, out.to(torch.bfloat16), beta=1.0, compute="bf16")
 
 
-@pytest.mark.parametrize("M,V,E", [(96, 1200, 300), (130, 2056, 64)])
-def test_gemm_bf16_stored_logits_chain(dev, M, V, E):
+@pytest.mark.parametrize("bb", [False, True])
+@pytest.mark.parametrize("M,V,E", [(96, 1200, 300), (130, 2056, 64), (264, 1032, 304), (520, 777 + 7, 300)])
+def test_gemm_bf16_stored_logits_chain(dev, M, V, E, bb, monkeypatch):
     """The generator's output layer with the logits-sized tensors held in bfloat16, product by product:
     vocabulary projection -> bf16 logits; softmax/NLL over bf16 logits; soft embedding with the exp loader over bf16
     logits; fused softmax backward reading bf16 logits in place, writing bf16 dlogits AND their transpose; dH and dW from
@@ -333,6 +334,9 @@ def test_gemm_bf16_stored_logits_chain(dev, M, V, E):
     rounding is measured): fp32 outputs 2e-5 (exp operand: 1e-2 bar of the mode, measured ~2e-3), bf16 outputs within
     one bf16 ulp (2^-8 relative) of the fp64 value."""
     ops = _ops()
+    # bb: every product the bf16 x bf16 kernel takes (M, N >= 128, K >= 64) runs there - projection with a bf16 result,
+    # exp loader, fused softmax backward with the transposed copy, dH, dW; otherwise the kernels that round at staging
+    monkeypatch.setattr(ops, "BB_MIN_FLOP", 0.0 if bb else 1e30)
     g = torch.Generator().manual_seed(M + V)
     H, tau = 64, 0.7
     h = torch.randn(M, H, generator=g)
@@ -741,3 +745,45 @@ def test_bf16_mode_routes_large_products_through_the_bb_kernel(dev, layout, monk
         assert _rel(outs[1], outs[0].double().cpu()) < 2e-6
         ref = _bf(hist[:, :T].reshape(-1, H).cpu()) @ _bf(B)
         assert _rel(outs[1], ref) < 2e-6
+
+
+@pytest.mark.parametrize("tile", [192, 256])
+@pytest.mark.parametrize("M,V,E,ldpad", [(264, 1032, 304, 0), (300, 791, 96, 1), (130, 520, 64, 0)])
+def test_gemm_bb_softmax_backward_and_exp_operand(dev, M, V, E, ldpad, tile):
+    """The two logits-sized products over bf16 logits on both tiles that carry them: fused softmax / CE backward in place
+    with the transposed copy (16-byte row paths and, with odd leading dimensions, the scalar ones), and the exp loader.
+    Against fp64 math on the same bf16 inputs."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 3 + V)
+    tau = 0.8
+    L0 = (torch.randn(M, V, generator=g) * 2).to(dev).bfloat16()
+    buf = torch.zeros(M, V + ldpad, device=dev, dtype=torch.bfloat16)
+    logits = buf[:, :V]
+    logits.copy_(L0)
+    Ld = L0.double()
+    lse = torch.logsumexp(Ld / tau, 1)
+    lse32 = lse.float()
+    P = torch.exp(Ld / tau - lse32.double()[:, None])
+    tgt = torch.randint(0, V, (M,), generator=g).to(dev)
+    emb = (torch.randn(V, E, generator=g) * 0.5).to(dev).bfloat16()      # [N = V rows, K = E]
+    dout = torch.randn(M, E, generator=g).to(dev).bfloat16()
+    # exp loader: softmax(L / tau) @ emb (B operand [N = E, K = V])
+    if E >= 128:
+        out_emb = torch.full((M, E), float("nan"), device=dev)
+        ops.gemm_bb(logits if ldpad == 0 else L0, emb.t().contiguous(), out_emb, a_exp=(1.0 / tau, lse32),
+                    force_tile=tile if tile != 192 or True else 0)
+        assert _rel(out_emb, (P @ emb.double()).cpu()) < 1e-2
+    rowdot = torch.randn(M, generator=g).to(dev)
+    ce_scale = 79.0 / tau / M
+    ct_buf = torch.full((V, M + 8 + ldpad), float("nan"), device=dev, dtype=torch.bfloat16)
+    ct = ct_buf[:, :M]
+    ops.gemm_bb(dout, emb, logits, c_t=ct, force_tile=tile,
+                softmax_bwd=dict(logits=logits, lse=lse32, rowdot=rowdot, target=tgt, inv_tau=1.0 / tau, ce_scale=ce_scale))
+    acc = dout.double() @ emb.double().t()
+    onehot = torch.zeros(M, V, dtype=torch.float64, device=dev)
+    onehot[torch.arange(M, device=dev), tgt] = 1.0
+    ref = P * (acc - rowdot.double()[:, None]) / tau + ce_scale * (P - onehot)
+    got = logits.double()
+    assert ((got - ref).abs() <= ref.abs() * 2.0 ** -7 + 1e-5 * ref.abs().max()).all()
+    assert torch.equal(ct, logits.t())
+    assert bool((buf[:, V:] == 0).all()) and bool(torch.isnan(ct_buf[:, M:].float()).all())
