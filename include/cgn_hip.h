@@ -201,6 +201,9 @@ typedef struct cgn_lstm_fwd_seq {
     float* gates;
     int32_t reverse;
     int32_t init_zero; /* 1: zero initial state (nn.LSTM called without (h0,c0)); the library zeroes the initial slots */
+    /* nullable, persistent entry points only: bf16 scratch of 2*B*H elements (16-byte aligned) through which the
+     * workgroups hand h_t to each other in operand mode 2 (cgn_lstm_set_operand_mode); contents need not survive */
+    void* handoff;
 } cgn_lstm_fwd_seq;
 
 int cgn_lstm_seq_fwd_f32(void* stream, const cgn_lstm_fwd_seq* seqs /* host */, int32_t nseq, int32_t B, int32_t T,
@@ -208,10 +211,17 @@ int cgn_lstm_seq_fwd_f32(void* stream, const cgn_lstm_fwd_seq* seqs /* host */, 
 
 /* Operand mode of the recurrences, process-wide (read at launch time; a captured hipGraph keeps the kernels it was
  * captured with): 0 (default) = every recurrent product at fp32 accuracy (fp32 MFMA, or X6 where the three-term weight
- * slice fits the registers: H <= 512); 1 = the optional bf16 mode (north_star: <= 1e-2): the row-tiled persistent
- * kernels at H > 512 form h.W_hh^T / dgates.W_hh from TWO-term bf16 splits of both operands (a0b0 + a0b1 + a1b0 on
- * v_mfma_f32_16x16x32_bf16, fp32 accumulation, ~2^-16 relative per product; the two-term weight slice takes the same
- * 128 registers as the fp32 one). No counterpart in the reference (nn.LSTM, model/encoder.py:17-21, generator.py:17-20). */
+ * slice fits the registers: H <= 512). 1, 2 = the optional bf16 mode (north_star: <= 1e-2) for the row-tiled
+ * persistent kernels at H > 512:
+ *   1: h.W_hh^T / dgates.W_hh from TWO-term bf16 splits of both operands (a0b0 + a0b1 + a1b0 on
+ *      v_mfma_f32_16x16x32_bf16, fp32 accumulation, ~2^-16 relative per product; the two-term weight slice takes the
+ *      same 128 registers as the fp32 one);
+ *   2: plain bf16 operands (what every other product of the mode uses), and the workgroups hand h_t / dgates_t to each
+ *      other as bf16 through the sequences' `handoff` scratch (a quarter of the bytes, an eighth of the L2 requests of
+ *      the fp32 history buffers: the recurrence at H = 1024 is paced by those requests). Needs H % 256 == 0 and a
+ *      handoff scratch on every sequence of the launch; launches without run as mode 1.
+ * Cell state, gates, accumulation and everything written to the history buffers stay fp32 in all modes.
+ * No counterpart in the reference (nn.LSTM, model/encoder.py:17-21, generator.py:17-20). */
 int cgn_lstm_set_operand_mode(int32_t mode);
 
 /* Persistent form of the two recurrences: ONE launch runs all T timesteps with the workgroup's W_hh slice, c_t / dc_t
@@ -263,6 +273,7 @@ typedef struct cgn_lstm_bwd_seq {
     float* dc_state;
     int64_t dh_bs, dh_ts;
     int32_t reverse;
+    void* handoff; /* nullable, persistent entry point only: bf16 scratch of 2*B*4H elements, as cgn_lstm_fwd_seq.handoff */
 } cgn_lstm_bwd_seq;
 
 int cgn_lstm_seq_bwd_f32(void* stream, const cgn_lstm_bwd_seq* seqs /* host */, int32_t nseq, int32_t B, int32_t T,

@@ -37,6 +37,7 @@ struct FwdSeq {
     float* gates;
     int reverse;
     int init_zero;
+    unsigned short* hx;  // bf16 hand-off scratch (operand mode 2), see lstm_persist_fwd_rt_kernel
 };
 struct FwdParams {
     FwdSeq s[LSTM_MAX_SEQ];
@@ -54,6 +55,7 @@ struct BwdSeq {
     float* dc_state;
     long dh_bs, dh_ts;
     int reverse;
+    unsigned short* hx;  // bf16 hand-off scratch (operand mode 2)
 };
 struct BwdParams {
     BwdSeq s[LSTM_MAX_SEQ];
@@ -363,6 +365,33 @@ __device__ __forceinline__ f32x4 ld4_sc1(__amdgpu_buffer_rsrc_t rsrc, int byte_o
 __device__ __forceinline__ void st_sc1(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword ... sc1
 }
+__device__ __forceinline__ void st_sc1(unsigned* p, unsigned v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// bf16 hand-off (operand mode 2, "X1"). At H = 1024 a step of the row-tiled recurrence is paced by L2 REQUESTS, not by
+// latency or the matrix pipe: every workgroup re-reads the 64 rows of its batch tile (h_t: 256 KB, dgates_t: 1 MB) as
+// 64-byte row segments of the fp32 history buffers (halving the loads of the backward kernel took it from 33 to 20 us
+// per step; deeper prefetch changed nothing). So the producers ALSO write what they hand over as bf16 into a small
+// scratch, blocked [parity][k / 8][B][8]: a consumer lane's 8 k of one row are ONE 16-byte load, the 16 rows of a
+// wave's load are 256 contiguous bytes (whole 128-byte lines), a quarter of the bytes and an eighth of the requests.
+// Two parities (step & 1): a workgroup writes step s+1's values only after every member of its group has finished
+// step s, i.e. has read step s-1's. The fp32 history buffers are still written (the GEMMs behind the recurrence read
+// them); nothing in the kernel reads them back.
+__device__ __forceinline__ long hx_off(int par, int KG, int kg, int B, int b) {  // element offset of (parity, k group, row)
+    return ((long)(par * KG + kg) * B + b) * 8;
+}
+__device__ __forceinline__ unsigned pack_bf16x2_lstm(float a, float b) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t v;
+    v[0] = (__bf16)a;
+    v[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+// the value of lane + 1 (same row, next unit) joins this lane's: even lanes store the pair as one 4-byte sc1 word
+__device__ __forceinline__ void hx_store_pair(unsigned short* hx, long elem_off, float v, int lane) {
+    const float nb = __shfl_down(v, 1, 64);
+    if (!(lane & 1)) st_sc1(reinterpret_cast<unsigned*>(hx + elem_off), pack_bf16x2_lstm(v, nb));
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // X6: the recurrent products on the bf16 matrix cores at fp32 accuracy.
@@ -402,8 +431,14 @@ __device__ __forceinline__ Frag3 split3(const f32x4& u, const f32x4& v) {
 // NP = 3: the six products above (fp32 accuracy). NP = 2 ("X3", the optional bf16 mode's row-tiled recurrences at
 // H > 512, cgn_lstm_set_operand_mode): two-term operands, a0b0 + a0b1 + a1b0, ~2^-16 relative per product - 250x finer
 // than bf16 operands, half the registers of the three-term weight slice (the same 128 VGPRs as the fp32 slice at H = 1024).
+// NP = 1 ("X1", operand mode 2): plain bf16 operands, one product (only the p0 parts are read; the others are dead code).
 template <int NG, int NP = 3>
 __device__ __forceinline__ void mfma_x6(const Frag3& a, const Frag3 (&b)[NG], f32x4 (&acc)[NG]) {
+    if constexpr (NP == 1) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = CGN_MFMA_BF16(a.p0, b[g].p0, acc[g]);
+        return;
+    }
     if constexpr (NP == 3) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) acc[g] = CGN_MFMA_BF16(a.p0, b[g].p2, acc[g]);
@@ -422,6 +457,7 @@ __device__ __forceinline__ void mfma_x6(const Frag3& a, const Frag3 (&b)[NG], f3
 // one accumulator chain (backward kernels: two chains, even / odd chunk pairs)
 template <int NP = 3>
 __device__ __forceinline__ f32x4 mfma_x6(const Frag3& a, const Frag3& b, f32x4 acc) {
+    if constexpr (NP == 1) return CGN_MFMA_BF16(a.p0, b.p0, acc);
     if constexpr (NP == 3) {
         acc = CGN_MFMA_BF16(a.p0, b.p2, acc);
         acc = CGN_MFMA_BF16(a.p2, b.p0, acc);
@@ -723,10 +759,19 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdPara
 // 32 KB reduction buffer; hand-off, counters and timeouts are those of the kernels above (one group = the workgroups
 // that share a 16RT-row batch tile). RT = 1, H <= 512 keeps the kernels above.
 // ------------------------------------------------------------------------------------------------------------------
-template <int CPW, int RT, int XM>  // XM: 0 = fp32 MFMA, 3 = X6, 2 = X3 (two-term operands: the bf16 mode, H > 512)
+// XM: 0 = fp32 MFMA, 3 = X6, 2 = X3 (two-term operands), 1 = X1 (plain bf16 operands; the bf16 mode at H > 512). X1's
+// weight slice takes a quarter of the registers of the fp32 one (a bf16x8 per 8 k and gate instead of two f32x4), which
+// buys what the recurrence at H = 1024 lacks: loads in flight. Forward: the h rows of ALL row tiles of a step are
+// requested up to two row tiles ahead (three register buffers: one exposed L2 round trip per step instead of one per
+// row tile); backward: the gradient rows travel 8 chunks at a time through three register buffers, the next two batches
+// (of this or the next row tile) on their way while the current one is multiplied (one exposed round trip per step
+// instead of sixteen).
+template <int CPW, int RT, int XM>
 __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdParams p, unsigned* sync, unsigned* sticky) {
     constexpr bool X6 = XM != 0;
-    static_assert(XM == 0 || XM == 2 || XM == 3, "operand mode");
+    constexpr int NPT = XM == 2 ? 2 : XM == 1 ? 1 : 3;  // bf16 terms per operand
+    constexpr bool PRE = XM == 1;                       // all row tiles' loads in flight at once
+    static_assert(XM >= 0 && XM <= 3, "operand mode");
     static_assert(CPW % 2 == 0 && (XM != 3 || CPW <= 4), "X6: chunk pairs; the three-term weight slice of H = 1024 does not fit the registers");
     __shared__ float red[LSTM_NW][16][64];
     __shared__ int s_ok;
@@ -748,11 +793,13 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdP
     const long gate_stride = (long)H * H;
     f32x4 w[X6 ? 1 : 4][X6 ? 1 : CPW];
     Frag3 w3[X6 ? CPW / 2 : 1][X6 ? 4 : 1];  // [chunk pair][gate]
+    // X1: a lane's 8 k of a chunk pair are CONSECUTIVE (k = 32 pair + 8 q ...: one 16-byte load of the bf16 hand-off
+    // scratch); the other forms take quad q of both chunks. (host: X1 only with whole chunk pairs per wave, H % 256 == 0)
     int koff[CPW];
 #pragma unroll
     for (int u = 0; u < CPW; ++u) {
         const bool ok = (u < cpw) && (c_beg + u < nchunks);
-        const int kc = ok ? (c_beg + u) * 16 + q * 4 : 0;
+        const int kc = !ok ? 0 : (XM == 1 ? (c_beg + (u & ~1)) * 16 + q * 8 + 4 * (u & 1) : (c_beg + u) * 16 + q * 4);
         koff[u] = kc * 4;
     }
 #pragma unroll
@@ -780,6 +827,9 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdP
     }
     const __amdgpu_buffer_rsrc_t hres =
         __builtin_amdgcn_make_buffer_rsrc((void*)sq.hbuf, 0, B * (T + 1) * H * 4, 0x00020000);
+    const int KG = H / 8;  // X1: k groups of the hand-off scratch [2][KG][B][8] bf16
+    const __amdgpu_buffer_rsrc_t xres =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(XM == 1 ? (void*)sq.hx : (void*)sq.hbuf), 0, 2 * KG * B * 16, 0x00020000);
 
     // cell-update elements of this thread (waves 0..3): row (lane>>4)*4 + wave of EVERY row tile, unit lane&15
     const int er = wave & 3;
@@ -821,20 +871,52 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdP
             __syncthreads();
             if (!s_ok) break;  // workgroup-uniform
         }
+        constexpr int NBUF = PRE ? 3 : 1;  // PRE: the h rows of the next two row tiles are in flight under the current one
+        f32x4 a[NBUF][PRE ? CPW / 2 : CPW];  // X1: a 16-byte load = the lane's 8 bf16 of one chunk pair
+        auto issue = [&](int buf, int rt) {
+            if constexpr (XM == 1) {
+                const int xoff = (int)hx_off((step + 1) & 1, KG, c_beg * 2 + q, B, min(b0 + rt * 16 + fr, B - 1)) * 2;
+#pragma unroll
+                for (int u = 0; u < CPW / 2; ++u) {
+                    // (pairs beyond this wave's range hold zero weights; their loads re-read pair 0: finite values)
+                    const int pu = (2 * u < cpw && c_beg + 2 * u < nchunks) ? u : 0;
+                    a[buf][u] = ld4_sc1(xres, xoff + pu * (4 * B * 16));
+                }
+            } else {
+                const int hoff = (min(b0 + rt * 16 + fr, B - 1) * (T + 1) + slot_prev) * H * 4;
+#pragma unroll
+                for (int u = 0; u < CPW; ++u) a[buf][u] = ld4_sc1(hres, hoff + koff[u]);
+            }
+        };
+        if constexpr (PRE) {
+            if (step > 0 || !sq.init_zero) {
+#pragma unroll
+                for (int rt = 0; rt < NBUF - 1 && rt < RT; ++rt) issue(rt, rt);
+            }
+        }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             f32x4 acc[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[g] = {0.f, 0.f, 0.f, 0.f};
             if (step > 0 || !sq.init_zero) {
-                const int bA = min(b0 + rt * 16 + fr, B - 1);
-                const int hoff = (bA * (T + 1) + slot_prev) * H * 4;
-                f32x4 a[CPW];
+                constexpr int ar = PRE ? 1 : 0;
+                if constexpr (PRE) {
+                    if (rt + NBUF - 1 < RT) issue((rt + NBUF - 1) % NBUF, rt + NBUF - 1);
+                } else {
+                    issue(0, rt);
+                }
+                if constexpr (XM == 1) {
 #pragma unroll
-                for (int u = 0; u < CPW; ++u) a[u] = ld4_sc1(hres, hoff + koff[u]);
-                if constexpr (X6) {
+                    for (int u = 0; u < CPW; u += 2) {
+                        Frag3 f;
+                        f.p0 = __builtin_bit_cast(bf16x8_t, a[rt % NBUF][u / 2]);
+                        mfma_x6<4, 1>(f, w3[u / 2], acc);
+                    }
+                } else if constexpr (X6) {
 #pragma unroll
-                    for (int u = 0; u < CPW; u += 2) mfma_x6<4, XM == 2 ? 2 : 3>(split3(a[u], a[u + 1]), w3[u / 2], acc);
+                    for (int u = 0; u < CPW; u += 2)
+                        mfma_x6<4, NPT>(split3(a[ar * (rt % NBUF)][u], a[ar * (rt % NBUF)][u + 1]), w3[u / 2], acc);
                 } else {
 #pragma unroll
                     for (int u = 0; u < CPW; ++u) {
@@ -842,7 +924,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdP
                         for (int i = 0; i < 4; ++i) {
 #pragma unroll
                             for (int g = 0; g < 4; ++g)
-                                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], w[g][u][i], acc[g], 0, 0, 0);
+                                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][u][i], w[g][u][i], acc[g], 0, 0, 0);
                         }
                     }
                 }
@@ -877,6 +959,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdP
                 go[3 * H + ej] = og;
                 sq.cbuf[((long)eb * (T + 1) + slot_out) * H + ej] = cn;
                 st_sc1(sq.hbuf + ((long)eb * (T + 1) + slot_out) * H + ej, hn);
+                if constexpr (XM == 1) hx_store_pair(sq.hx, hx_off(step & 1, KG, ej >> 3, B, eb) + (ej & 7), hn, lane);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the arrival is signalled
@@ -889,12 +972,15 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdP
 
 // CPW: chunks (of 16 k over K = 4H) per wave held in registers (H <= 32 * CPW); the gradient rows are loaded CB chunks at
 // a time (32 VGPRs) so that the 128-VGPR weight slice of H = 1024 leaves room for them.
-template <int CPW, int RT, int XM>  // XM: 0 = fp32 MFMA, 3 = X6, 2 = X3 (two-term operands: the bf16 mode, H > 512)
+template <int CPW, int RT, int XM>  // XM: see lstm_persist_fwd_rt_kernel
 __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_rt_kernel(const BwdParams p, unsigned* sync, unsigned* sticky) {
     constexpr bool X6 = XM != 0;
+    constexpr int NPT = XM == 2 ? 2 : XM == 1 ? 1 : 3;
+    constexpr bool PIPE = XM == 1;  // NBUF register buffers of CB chunks: the next NBUF-1 batches in flight under the current one
     constexpr int CB = CPW < 8 ? CPW : 8;
+    constexpr int NBUF = PIPE ? 3 : 1;
     static_assert(CPW % CB == 0 && CB % 4 == 0, "chunk batches; two accumulator chains over chunk pairs");
-    static_assert(XM == 0 || XM == 2 || (XM == 3 && CPW <= 16), "the three-term weight slice of H = 1024 does not fit the registers");
+    static_assert(XM == 0 || XM == 1 || XM == 2 || (XM == 3 && CPW <= 16), "the three-term weight slice of H = 1024 does not fit the registers");
     __shared__ float red[LSTM_NW][4][64];
     __shared__ int s_ok;
     const int B = p.B, T = p.T, H = p.H;
@@ -921,7 +1007,8 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_rt_kernel(const BwdP
 #pragma unroll
         for (int u = 0; u < CPW; ++u) {
             const bool ok = (u < cpw) && (c_beg + u < nchunks);
-            const int kc = ok ? (c_beg + u) * 16 + q * 4 : 0;
+            // (X1: the lane's 8 k of a chunk pair are consecutive, as in the forward kernel)
+            const int kc = !ok ? 0 : (XM == 1 ? (c_beg + (u & ~1)) * 16 + q * 8 + 4 * (u & 1) : (c_beg + u) * 16 + q * 4);
             f32x4 v;
             if (sq.w_hh) {
 #pragma unroll
@@ -940,6 +1027,9 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_rt_kernel(const BwdP
         }
     }
     const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void*)sq.dgates, 0, B * T * K * 4, 0x00020000);
+    const int KG = K / 8;  // X1: k groups of the hand-off scratch [2][KG][B][8] bf16
+    const __amdgpu_buffer_rsrc_t xres =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(XM == 1 ? (void*)sq.hx : (void*)sq.dgates), 0, 2 * KG * B * 16, 0x00020000);
 
     const int er = wave & 3;
     const int ej = j0 + (lane & 15);
@@ -961,6 +1051,33 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_rt_kernel(const BwdP
             __syncthreads();
             if (!s_ok) break;  // workgroup-uniform
         }
+        constexpr int NBR = CPW / CB;  // batches per row tile
+        f32x4 ab[NBUF][PIPE ? CB / 2 : CB];  // X1: a 16-byte load = the lane's 8 bf16 of one chunk pair
+        auto issue = [&](int buf, int rt, int bi) {  // the loads of batch bi of row tile rt into register buffer buf
+            if constexpr (XM == 1) {
+                const int xoff = (int)hx_off((step + 1) & 1, KG, c_beg * 2 + q, B, min(b0 + rt * 16 + fr, B - 1)) * 2;
+#pragma unroll
+                for (int u = 0; u < CB / 2; ++u) {
+                    const int c = bi * CB + 2 * u;  // first chunk of the pair; pairs beyond the wave's range re-read pair 0
+                    const int pu = (c < cpw && c_beg + c < nchunks) ? c / 2 : 0;
+                    ab[buf][u] = ld4_sc1(xres, xoff + pu * (4 * B * 16));
+                }
+                return;
+            }
+            const int aoff = (min(b0 + rt * 16 + fr, B - 1) * T + t_next) * K * 4 + kbase;
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                // chunks beyond this wave's range hold zero weights; their (clamped) loads re-read chunk 0
+                const int cu = (bi * CB + u < cpw && c_beg + bi * CB + u < nchunks) ? (bi * CB + u) : 0;
+                ab[buf][u] = ld4_sc1(dres, aoff + cu * 64);
+            }
+        };
+        if constexpr (PIPE) {
+            if (step > 0) {
+#pragma unroll
+                for (int n = 0; n < NBUF - 1 && n < RT * NBR; ++n) issue(n, n / NBR, n % NBR);
+            }
+        }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const int eb = b0 + rt * 16 + (lane >> 4) * 4 + er;
@@ -974,22 +1091,32 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_rt_kernel(const BwdP
 
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             if (step > 0) {
-                const int bA = min(b0 + rt * 16 + fr, B - 1);
-                const int aoff = (bA * T + t_next) * K * 4 + kbase;
 #pragma unroll
-                for (int c0 = 0; c0 < CPW; c0 += CB) {
-                    f32x4 a[CB];
-#pragma unroll
-                    for (int u = 0; u < CB; ++u) {
-                        // chunks beyond this wave's range hold zero weights; their (clamped) loads re-read chunk 0
-                        const int cu = (c0 + u < cpw && c_beg + c0 + u < nchunks) ? (c0 + u) : 0;
-                        a[u] = ld4_sc1(dres, aoff + cu * 64);
+                for (int bi = 0; bi < NBR; ++bi) {
+                    const int c0 = bi * CB;
+                    const int n = rt * NBR + bi;  // batch number within the step
+                    const int cur = PIPE ? (n % NBUF) : 0;
+                    if constexpr (PIPE) {
+                        constexpr int D = NBUF - 1;
+                        if (n + D < RT * NBR) issue((n + D) % NBUF, (n + D) / NBR, (n + D) % NBR);
+                    } else {
+                        issue(0, rt, bi);
                     }
-                    if constexpr (X6) {
+                    auto& a = ab[cur];
+                    if constexpr (XM == 1) {
 #pragma unroll
                         for (int u = 0; u < CB; u += 4) {
-                            acc0 = mfma_x6<XM == 2 ? 2 : 3>(split3(a[u], a[u + 1]), w3[(c0 + u) / 2], acc0);
-                            acc1 = mfma_x6<XM == 2 ? 2 : 3>(split3(a[u + 2], a[u + 3]), w3[(c0 + u) / 2 + 1], acc1);
+                            Frag3 f0, f1;
+                            f0.p0 = __builtin_bit_cast(bf16x8_t, a[u / 2]);
+                            f1.p0 = __builtin_bit_cast(bf16x8_t, a[u / 2 + 1]);
+                            acc0 = mfma_x6<1>(f0, w3[(c0 + u) / 2], acc0);
+                            acc1 = mfma_x6<1>(f1, w3[(c0 + u) / 2 + 1], acc1);
+                        }
+                    } else if constexpr (X6) {
+#pragma unroll
+                        for (int u = 0; u < CB; u += 4) {
+                            acc0 = mfma_x6<NPT>(split3(a[u], a[u + 1]), w3[(c0 + u) / 2], acc0);
+                            acc1 = mfma_x6<NPT>(split3(a[u + 2], a[u + 3]), w3[(c0 + u) / 2 + 1], acc1);
                         }
                     } else {
 #pragma unroll
@@ -1016,10 +1143,20 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_rt_kernel(const BwdP
                 const float tc = tanhf(cout);
                 const float dc = dc_reg[rt] + dh * og * (1.f - tc * tc);
                 float* dg = sq.dgates + ((long)eb * T + t) * K;
-                st_sc1(dg + ej, dc * gg * ig * (1.f - ig));
-                st_sc1(dg + H + ej, dc * cprev * fg * (1.f - fg));
-                st_sc1(dg + 2 * H + ej, dc * ig * (1.f - gg * gg));
-                st_sc1(dg + 3 * H + ej, dh * tc * og * (1.f - og));
+                const float d0 = dc * gg * ig * (1.f - ig), d1 = dc * cprev * fg * (1.f - fg);
+                const float d2 = dc * ig * (1.f - gg * gg), d3 = dh * tc * og * (1.f - og);
+                st_sc1(dg + ej, d0);
+                st_sc1(dg + H + ej, d1);
+                st_sc1(dg + 2 * H + ej, d2);
+                st_sc1(dg + 3 * H + ej, d3);
+                if constexpr (XM == 1) {
+                    const long xo = hx_off(step & 1, KG, ej >> 3, B, eb) + (ej & 7);
+                    const long gs = (long)(H / 8) * B * 8;  // elements between the gates' k groups (k = g H + unit)
+                    hx_store_pair(sq.hx, xo, d0, lane);
+                    hx_store_pair(sq.hx, xo + gs, d1, lane);
+                    hx_store_pair(sq.hx, xo + 2 * gs, d2, lane);
+                    hx_store_pair(sq.hx, xo + 3 * gs, d3, lane);
+                }
                 dc_reg[rt] = dc * fg;
             }
         }
@@ -1460,8 +1597,8 @@ int g_num_cus[16] = {0};
 // consumer wave splits its share again (64 values per lane and step: ~1 us of VALU work on a SIMD that two waves
 // share), which eats the MFMA time saved. (Splitting once at the producer and handing the bf16 parts over is the
 // next step.) CGN_LSTM_X6=0 / CGN_LSTM_X6_BWD=1 override (A/B measurements).
-// 0 = every recurrence at fp32 accuracy (default); 1 = the optional bf16 mode: the row-tiled recurrences at H > 512 take
-// two-term bf16 operands (cgn_lstm_set_operand_mode, include/cgn_hip.h)
+// 0 = every recurrence at fp32 accuracy (default); the optional bf16 mode: the row-tiled recurrences at H > 512 take
+// two-term (1) or plain (2) bf16 operands (cgn_lstm_set_operand_mode, include/cgn_hip.h)
 int g_lstm_operand_mode = 0;
 
 bool lstm_x6() {
@@ -1607,6 +1744,21 @@ extern "C" int cgn_lstm_seq_bwd_f32(void* stream, const cgn_lstm_bwd_seq* seqs, 
     return CGN_OK;
 }
 
+namespace {
+// operand mode 2, sequences with a given initial state: bf16(h_init) into parity 1 of the hand-off scratch
+// [2][H / 8][B][8] (the parity step 0 reads); two units per thread
+__global__ __launch_bounds__(256) void lstm_handoff_init_kernel(const FwdParams p) {
+    const FwdSeq& sq = p.s[blockIdx.y];
+    if (sq.init_zero || !sq.hx) return;
+    const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int hp = p.H / 2;
+    if (v >= (long)p.B * hp) return;
+    const int b = (int)(v / hp), j = (int)(v % hp) * 2;
+    const float* h = sq.hbuf + ((long)b * (p.T + 1) + (sq.reverse ? p.T : 0)) * p.H + j;
+    *reinterpret_cast<unsigned*>(sq.hx + hx_off(1, p.H / 8, j >> 3, p.B, b) + (j & 7)) = pack_bf16x2_lstm(h[0], h[1]);
+}
+}  // namespace
+
 extern "C" int cgn_lstm_persistent_query(int32_t nseq, int32_t B, int32_t T, int32_t H, int64_t* sync_bytes) {
     CGN_CHECK_ARG(sync_bytes != nullptr);
     *sync_bytes = persist_rt(nseq, B, T, H) ? persist_sync_bytes(nseq, B) : 0;
@@ -1627,7 +1779,8 @@ extern "C" int cgn_lstm_seq_fwd_persistent_f32(void* stream, const cgn_lstm_fwd_
         const cgn_lstm_fwd_seq& s = seqs[i];
         CGN_CHECK_ARG(s.xg && s.w_hh && s.hbuf && s.cbuf && s.gates);
         CGN_CHECK_ARG(((uintptr_t)s.hbuf % 16 == 0) && ((uintptr_t)s.w_hh % 16 == 0));
-        p.s[i] = {s.xg, s.xg_extra, s.w_hh, s.hbuf, s.cbuf, s.gates, s.reverse, s.init_zero};
+        CGN_CHECK_ARG((uintptr_t)s.handoff % 16 == 0);
+        p.s[i] = {s.xg, s.xg_extra, s.w_hh, s.hbuf, s.cbuf, s.gates, s.reverse, s.init_zero, (unsigned short*)s.handoff};
     }
     p.B = B; p.T = T; p.H = H; p.nseq = nseq; p.step = xcd_identity();
     hipStream_t st = (hipStream_t)stream;
@@ -1635,12 +1788,24 @@ extern "C" int cgn_lstm_seq_fwd_persistent_f32(void* stream, const cgn_lstm_fwd_
     dim3 grid(nseq * cgn_cdiv(B, 16 * rt) * (H / 16));
     unsigned* sw = (unsigned*)sync_ws;
     const bool x6 = lstm_x6();
+    // operand mode 2 runs the plain-bf16 kernels where every sequence brings its hand-off scratch and the waves own
+    // whole chunk pairs (H % 256 == 0); otherwise the two-term kernels
+    bool x1 = g_lstm_operand_mode == 2 && H > 512 && H % 256 == 0;
+    for (int i = 0; i < nseq; ++i) x1 = x1 && seqs[i].handoff != nullptr;
+    if (x1) {
+        bool any_init = false;
+        for (int i = 0; i < nseq; ++i) any_init = any_init || !seqs[i].init_zero;
+        if (any_init) {  // the given initial h as bf16 into parity 1 of the scratch: what step 0 reads
+            hipLaunchKernelGGL(lstm_handoff_init_kernel, dim3(cgn_cdiv((long)B * H / 2, 256), nseq), dim3(256), 0, st, p);
+            CGN_LAUNCH_CHECK();
+        }
+    }
 #define CGN_FWD_K(CPW) do { if (x6) hipLaunchKernelGGL((lstm_persist_fwd_kernel<CPW, true>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky); \
                             else hipLaunchKernelGGL((lstm_persist_fwd_kernel<CPW, false>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky); } while (0)
 #define CGN_FWD_RT(CPW, RT, X) hipLaunchKernelGGL((lstm_persist_fwd_rt_kernel<CPW, RT, X>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky)
 #define CGN_FWD_RTX(CPW, RT) do { if (x6) CGN_FWD_RT(CPW, RT, 3); else CGN_FWD_RT(CPW, RT, 0); } while (0)
     // H > 512: the three-term weight slice does not fit the registers; the two-term one does (the bf16 mode only)
-#define CGN_FWD_RTB(CPW, RT) do { if (g_lstm_operand_mode == 1) CGN_FWD_RT(CPW, RT, 2); else CGN_FWD_RT(CPW, RT, 0); } while (0)
+#define CGN_FWD_RTB(CPW, RT) do { if (x1) CGN_FWD_RT(CPW, RT, 1); else if (g_lstm_operand_mode != 0) CGN_FWD_RT(CPW, RT, 2); else CGN_FWD_RT(CPW, RT, 0); } while (0)
     if (rt == 1 && H <= 256) CGN_FWD_K(2);
     else if (rt == 1 && H <= 512) CGN_FWD_K(4);
     else if (rt == 1) CGN_FWD_RTB(8, 1);
@@ -1738,8 +1903,9 @@ extern "C" int cgn_lstm_seq_bwd_persistent_f32(void* stream, const cgn_lstm_bwd_
         const cgn_lstm_bwd_seq& s = seqs[i];
         CGN_CHECK_ARG((s.w_hh_t || s.w_hh) && s.cbuf && s.gates && s.dgates && s.dc_state);
         CGN_CHECK_ARG(((uintptr_t)s.dgates % 16 == 0) && ((uintptr_t)s.w_hh_t % 16 == 0));
+        CGN_CHECK_ARG((uintptr_t)s.handoff % 16 == 0);
         p.s[i] = {s.w_hh_t, s.w_hh, s.cbuf, s.gates, s.dh_ext, s.dh_seed, s.dgates, s.dc_state, s.dh_bs, s.dh_ts,
-                  s.reverse};
+                  s.reverse, (unsigned short*)s.handoff};
     }
     p.B = B; p.T = T; p.H = H; p.nseq = nseq; p.step = xcd_identity();
     hipStream_t st = (hipStream_t)stream;
@@ -1747,11 +1913,13 @@ extern "C" int cgn_lstm_seq_bwd_persistent_f32(void* stream, const cgn_lstm_bwd_
     dim3 grid(nseq * cgn_cdiv(B, 16 * rt) * (H / 16));
     unsigned* sw = (unsigned*)sync_ws;
     const bool x6 = lstm_x6_bwd();
+    bool x1 = g_lstm_operand_mode == 2 && H > 512 && H % 256 == 0;  // (as in the forward entry point)
+    for (int i = 0; i < nseq; ++i) x1 = x1 && seqs[i].handoff != nullptr;
 #define CGN_BWD_K(CPW) do { if (x6) hipLaunchKernelGGL((lstm_persist_bwd_kernel<CPW, true>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky); \
                             else hipLaunchKernelGGL((lstm_persist_bwd_kernel<CPW, false>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky); } while (0)
 #define CGN_BWD_RT(CPW, RT, X) hipLaunchKernelGGL((lstm_persist_bwd_rt_kernel<CPW, RT, X>), grid, dim3(LSTM_NT), 0, st, p, sw, sticky)
 #define CGN_BWD_RTX(CPW, RT) do { if (x6) CGN_BWD_RT(CPW, RT, 3); else CGN_BWD_RT(CPW, RT, 0); } while (0)
-#define CGN_BWD_RTB(CPW, RT) do { if (g_lstm_operand_mode == 1) CGN_BWD_RT(CPW, RT, 2); else CGN_BWD_RT(CPW, RT, 0); } while (0)
+#define CGN_BWD_RTB(CPW, RT) do { if (x1) CGN_BWD_RT(CPW, RT, 1); else if (g_lstm_operand_mode != 0) CGN_BWD_RT(CPW, RT, 2); else CGN_BWD_RT(CPW, RT, 0); } while (0)
     if (rt == 1 && H <= 256) CGN_BWD_K(8);
     else if (rt == 1 && H <= 512) CGN_BWD_K(16);
     else if (rt == 1) CGN_BWD_RTB(32, 1);
@@ -1833,7 +2001,7 @@ extern "C" int cgn_lstm2_bwd_persistent_f32(void* stream, const cgn_lstm2_bwd* d
 }
 
 extern "C" int cgn_lstm_set_operand_mode(int32_t mode) {
-    CGN_CHECK_ARG(mode == 0 || mode == 1);
+    CGN_CHECK_ARG(mode == 0 || mode == 1 || mode == 2);
     g_lstm_operand_mode = mode;
     return CGN_OK;
 }

@@ -72,12 +72,13 @@ class GemmBBDesc(C.Structure):
 
 class LstmFwdSeq(C.Structure):
     _fields_ = [("xg", c_ptr), ("xg_extra", c_ptr), ("w_hh", c_ptr), ("hbuf", c_ptr), ("cbuf", c_ptr),
-                ("gates", c_ptr), ("reverse", c_i32), ("init_zero", c_i32)]
+                ("gates", c_ptr), ("reverse", c_i32), ("init_zero", c_i32), ("handoff", c_ptr)]
 
 
 class LstmBwdSeq(C.Structure):
     _fields_ = [("w_hh_t", c_ptr), ("w_hh", c_ptr), ("cbuf", c_ptr), ("gates", c_ptr), ("dh_ext", c_ptr), ("dh_seed", c_ptr),
-                ("dgates", c_ptr), ("dc_state", c_ptr), ("dh_bs", c_i64), ("dh_ts", c_i64), ("reverse", c_i32)]
+                ("dgates", c_ptr), ("dc_state", c_ptr), ("dh_bs", c_i64), ("dh_ts", c_i64), ("reverse", c_i32),
+                ("handoff", c_ptr)]
 
 
 class Lstm2Fwd(C.Structure):

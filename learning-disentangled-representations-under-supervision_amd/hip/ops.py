@@ -48,9 +48,10 @@ def _compute_code(compute):
 BF16_STORAGE = os.environ.get("CGN_BF16_STORAGE", "1") != "0"
 
 
-# bf16 mode: the row-tiled recurrences at H > 512 take two-term bf16 operands (cgn_lstm_set_operand_mode);
-# CGN_LSTM_BF16_RT=0 keeps them on the fp32 MFMA (A/B switch)
-LSTM_BF16_RT = os.environ.get("CGN_LSTM_BF16_RT", "1") != "0"
+# bf16 mode: the row-tiled recurrences at H > 512 take bf16 operands (cgn_lstm_set_operand_mode): CGN_LSTM_BF16_RT=2
+# (default) plain bf16 operands with the hand-off loads pipelined, 1 two-term operands (~2^-16 per product), 0 keeps them
+# on the fp32 MFMA (A/B switch)
+LSTM_BF16_RT = int(os.environ.get("CGN_LSTM_BF16_RT", "2"))
 
 
 def _sync_lstm_operand_mode():
@@ -58,7 +59,7 @@ def _sync_lstm_operand_mode():
         lib = _lib.load()
     except RuntimeError:
         return  # (no library: every op raises on its own)
-    _lib.check(lib.cgn_lstm_set_operand_mode(1 if (COMPUTE == _lib.COMPUTE_BF16 and LSTM_BF16_RT) else 0),
+    _lib.check(lib.cgn_lstm_set_operand_mode(int(LSTM_BF16_RT) if COMPUTE == _lib.COMPUTE_BF16 else 0),
                "cgn_lstm_set_operand_mode")
 
 
@@ -1116,6 +1117,30 @@ def clear_lstm_sticky_timeouts():
         ws[-32:].zero_()
 
 
+def _lstm_handoff_wanted(H):
+    """bf16 mode with plain-bf16 recurrences (LSTM_BF16_RT == 2) at H > 512: the library wants a bf16 hand-off scratch
+    per sequence (include/cgn_hip.h cgn_lstm_fwd_seq.handoff)."""
+    return COMPUTE == _lib.COMPUTE_BF16 and int(LSTM_BF16_RT) == 2 and H > 512 and H % 256 == 0
+
+
+_lstm_handoff = {}
+
+
+def _lstm_handoff_scratch(dev, kind, i, nelem):
+    """bf16 hand-off scratch of sequence i of a launch. Inside a step (KEEP is a list) a fresh step-scoped tensor, like
+    every other temporary; otherwise one buffer per (device, stream, kind, i) that lives as long as the process: a
+    temporary would go back to torch's allocator before the launch has run and could be handed out again right away
+    (the first call did exactly that: the LSTM counter workspace, allocated next, got the block)."""
+    if KEEP is not None:
+        return alloc((nelem,), dev, torch.bfloat16)
+    idx = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream, kind, i)
+    t = _lstm_handoff.get(key)
+    if t is None or t.numel() < nelem:
+        t = _lstm_handoff[key] = torch.empty(nelem, dtype=torch.bfloat16, device=torch.device("cuda", idx))
+    return t
+
+
 def lstm_seq_fwd(seqs, B, T, H):
     """seqs: list of dicts(xg, xg_extra=None, w_hh, hbuf, cbuf, gates, reverse)."""
     arr = (_lib.LstmFwdSeq * len(seqs))()
@@ -1136,6 +1161,9 @@ def lstm_seq_fwd(seqs, B, T, H):
         arr[i].init_zero = 1 if s.get("init_zero") else 0
     grp = lstm_persistent_group(len(seqs), B, T, H, dev)
     if grp:
+        if _lstm_handoff_wanted(H):
+            for i in range(len(seqs)):  # bf16 hand-off scratch [2][H/8][B][8] per sequence (operand mode 2)
+                arr[i].handoff = _lstm_handoff_scratch(dev, "fwd", i, 2 * B * H).data_ptr()
         ws = _lstm_sync_ws(dev)
         for i in range(0, len(seqs), grp):
             sub = (_lib.LstmFwdSeq * grp).from_buffer(arr, i * C.sizeof(_lib.LstmFwdSeq))
@@ -1181,6 +1209,9 @@ def lstm_seq_bwd(seqs, B, T, H):
         arr[i].dgates, arr[i].dc_state = s["dgates"].data_ptr(), s["dc_state"].data_ptr()
         arr[i].reverse = 1 if s.get("reverse") else 0
     if grp:
+        if _lstm_handoff_wanted(H):
+            for i in range(len(seqs)):
+                arr[i].handoff = _lstm_handoff_scratch(dev, "bwd", i, 2 * B * 4 * H).data_ptr()
         ws = _lstm_sync_ws(dev)
         for i in range(0, len(seqs), grp):
             sub = (_lib.LstmBwdSeq * grp).from_buffer(arr, i * C.sizeof(_lib.LstmBwdSeq))

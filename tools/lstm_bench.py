@@ -35,6 +35,10 @@ def seqs(n, B, T, H, revs):
     return out
 
 
+if os.environ.get("CGN_LSTM_OPERAND_MODE"):  # 0 fp32 accuracy | 1 two-term | 2 plain bf16 operands (row-tiled kernels at H > 512)
+    from ldrs_amd.hip import _lib
+    _lib.check(_lib.load().cgn_lstm_set_operand_mode(int(os.environ["CGN_LSTM_OPERAND_MODE"])), "cgn_lstm_set_operand_mode")
+    print("operand mode", os.environ["CGN_LSTM_OPERAND_MODE"])
 B, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (64, 512)
 T0 = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 print("B %d H %d: sequences per persistent launch: encoder %d, generator layer %d" % (
@@ -43,11 +47,11 @@ for name, T, revs in (("encoder biLSTM (2 sequences)", T0, (False, True)), ("one
     ss = seqs(len(revs), B, T, H, revs)
     W = [torch.randn(4 * H, H, device=dev) / H ** 0.5 for _ in revs]
     us = timeit(lambda: engine.lstm_run_fwd(ss, W))
-    print("%-32s fwd  %7.1f us  %5.2f us/step" % (name, us, us / T))
+    print("%-32s fwd  %7.1f us  %5.2f us/step   (sticky %d)" % (name, us, us / T, ops.lstm_sticky_timeouts()))
     dh = torch.randn(B, T, H, device=dev)
     dcs = [torch.zeros(B, H, device=dev) for _ in revs]
     us = timeit(lambda: engine.lstm_run_bwd(ss, W, [(dh, T * H, H)] * len(revs), [None] * len(revs), dcs))
-    print("%-32s bwd  %7.1f us  %5.2f us/step" % (name, us, us / T))
+    print("%-32s bwd  %7.1f us  %5.2f us/step   (sticky %d)" % (name, us, us / T, ops.lstm_sticky_timeouts()))
 T = T0 + 1
 if not ops.lstm2_persistent_bytes(B, T, H, dev):
     print("two-layer wavefront form: shape not eligible; sticky timeouts:", ops.lstm_sticky_timeouts())
