@@ -527,6 +527,13 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_kernel(const FwdPara
     const int bA = min(b0 + fr, B - 1);
     const __amdgpu_buffer_rsrc_t hres =
         __builtin_amdgcn_make_buffer_rsrc((void*)sq.hbuf, 0, B * (T + 1) * H * 4, 0x00020000);
+    // fp32 hand-off scratch (nullable), blocked [parity][k / 4][B][4]: the 16 rows of a wave's load are 256 contiguous
+    // bytes (whole 128-byte lines) instead of sixteen 64-byte segments of the history buffer - the same bytes in half
+    // the L2 requests (see hx_off). Same values, same k order: results do not change by a bit.
+    float* hx32 = reinterpret_cast<float*>(sq.hx);
+    const int KG4 = H / 4;
+    const __amdgpu_buffer_rsrc_t xres =
+        __builtin_amdgcn_make_buffer_rsrc(hx32 ? (void*)hx32 : (void*)sq.hbuf, 0, 2 * KG4 * B * 16, 0x00020000);
 
     // the cell-update element of this thread (waves 0..3): row (lane>>4)*4 + wave, unit lane&15 -- fixed for all t
     const int er = wave & 3;
@@ -572,8 +579,15 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_kernel(const FwdPara
         if (step > 0 || !sq.init_zero) {  // uniform: h_{-1} = 0 contributes nothing
             const int hoff = (bA * (T + 1) + slot_prev) * H * 4;
             f32x4 a[CPW];
+            if (hx32 && step > 0) {  // (uniform; step 0 reads the given initial state from the history buffer)
+                // k group kc / 4 of row bA: byte offset ((kc / 4) * B + bA) * 16 = koff * B + bA * 16
+                const int xoff = (((step + 1) & 1) * KG4 * B + bA) * 16;
 #pragma unroll
-            for (int u = 0; u < CPW; ++u) a[u] = ld4_sc1(hres, hoff + koff[u]);
+                for (int u = 0; u < CPW; ++u) a[u] = ld4_sc1(xres, xoff + koff[u] * B);
+            } else {
+#pragma unroll
+                for (int u = 0; u < CPW; ++u) a[u] = ld4_sc1(hres, hoff + koff[u]);
+            }
             if constexpr (X6) {
 #pragma unroll
                 for (int u = 0; u < CPW; u += 2) mfma_x6<4>(split3(a[u], a[u + 1]), w3[u / 2], acc);
@@ -617,6 +631,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_kernel(const FwdPara
             go[3 * H + ej] = og;
             sq.cbuf[((long)eb * (T + 1) + slot_out) * H + ej] = cn;
             st_sc1(sq.hbuf + ((long)eb * (T + 1) + slot_out) * H + ej, hn);
+            if (hx32) st_sc1(hx32 + ((long)((step & 1) * KG4 + (ej >> 2)) * B + eb) * 4 + (ej & 3), hn);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the arrival is signalled
         __syncthreads();
@@ -678,6 +693,10 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdPara
     }
     const int bA = min(b0 + fr, B - 1);
     const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void*)sq.dgates, 0, B * T * K * 4, 0x00020000);
+    float* hx32 = reinterpret_cast<float*>(sq.hx);  // fp32 hand-off scratch [parity][k / 4][B][4], see the forward kernel
+    const int KG4 = K / 4;
+    const __amdgpu_buffer_rsrc_t xres =
+        __builtin_amdgcn_make_buffer_rsrc(hx32 ? (void*)hx32 : (void*)sq.dgates, 0, 2 * KG4 * B * 16, 0x00020000);
 
     const int er = wave & 3;
     const int eb = b0 + (lane >> 4) * 4 + er, ej = j0 + (lane & 15);
@@ -705,8 +724,14 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdPara
             if (!s_ok) break;  // workgroup-uniform
             const int aoff = (bA * T + t_next) * K * 4;
             f32x4 a[CPW];
+            if (hx32) {  // (uniform)
+                const int xoff = (((step + 1) & 1) * KG4 * B + bA) * 16;
 #pragma unroll
-            for (int u = 0; u < CPW; ++u) a[u] = ld4_sc1(dres, aoff + koff[u]);
+                for (int u = 0; u < CPW; ++u) a[u] = ld4_sc1(xres, xoff + koff[u] * B);
+            } else {
+#pragma unroll
+                for (int u = 0; u < CPW; ++u) a[u] = ld4_sc1(dres, aoff + koff[u]);
+            }
             if constexpr (X6) {
 #pragma unroll
                 for (int u = 0; u < CPW; u += 4) {
@@ -736,10 +761,20 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdPara
             const float tc = tanhf(cout);
             const float dc = dc_reg + dh * og * (1.f - tc * tc);
             float* dg = sq.dgates + ((long)eb * T + t) * K;
-            st_sc1(dg + ej, dc * gg * ig * (1.f - ig));
-            st_sc1(dg + H + ej, dc * cprev * fg * (1.f - fg));
-            st_sc1(dg + 2 * H + ej, dc * ig * (1.f - gg * gg));
-            st_sc1(dg + 3 * H + ej, dh * tc * og * (1.f - og));
+            const float d0 = dc * gg * ig * (1.f - ig), d1 = dc * cprev * fg * (1.f - fg);
+            const float d2 = dc * ig * (1.f - gg * gg), d3 = dh * tc * og * (1.f - og);
+            st_sc1(dg + ej, d0);
+            st_sc1(dg + H + ej, d1);
+            st_sc1(dg + 2 * H + ej, d2);
+            st_sc1(dg + 3 * H + ej, d3);
+            if (hx32) {  // k = gate * H + unit: the gates' k groups are H / 4 groups apart
+                float* xo = hx32 + ((long)((step & 1) * KG4 + (ej >> 2)) * B + eb) * 4 + (ej & 3);
+                const long gs = (long)(H / 4) * B * 4;
+                st_sc1(xo, d0);
+                st_sc1(xo + gs, d1);
+                st_sc1(xo + 2 * gs, d2);
+                st_sc1(xo + 3 * gs, d3);
+            }
             dc_reg = dc * fg;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1408,6 +1443,10 @@ struct Bwd2Params {
     float* dgates[2];
     long dh_bs, dh_ts;
     int B, T, H, flat;
+    // nullable: blocked fp32 copies [T][4H / 4][B][4] of both layers' gate gradients, what the workgroups read from each
+    // other (whole cache lines per load, see hx_off). Full histories, not two parities: the top layer runs ahead of the
+    // bottom one by any number of steps.
+    float* hx[2];
 };
 
 // role 0 = the TOP layer (layer 1: dh1_t = dH_ext[t] + W_hh1ᵀ·dg1_{t+1}), role 1 = the BOTTOM layer (layer 0:
@@ -1475,8 +1514,15 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_bwd_kernel(const Bwd2Pa
     }
     const int bA = min(b0 + fr, B - 1);
     const int dbytes = B * T * K4 * 4;
-    const __amdgpu_buffer_rsrc_t dres_own = __builtin_amdgcn_make_buffer_rsrc((void*)p.dgates[layer], 0, dbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t dres_top = __builtin_amdgcn_make_buffer_rsrc((void*)p.dgates[1], 0, dbytes, 0x00020000);
+    const bool blk = p.hx[0] != nullptr;  // blocked hand-off copies: the same values, same k order (bit-identical results)
+    const __amdgpu_buffer_rsrc_t dres_own =
+        __builtin_amdgcn_make_buffer_rsrc(blk ? (void*)p.hx[layer] : (void*)p.dgates[layer], 0, dbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dres_top =
+        __builtin_amdgcn_make_buffer_rsrc(blk ? (void*)p.hx[1] : (void*)p.dgates[1], 0, dbytes, 0x00020000);
+    const int KG4 = K4 / 4;
+    // byte offset of (timestep, row bA, quad q) and the scalar step per column: history [B,T,4H] | blocked [T][4H/4][B][4]
+    auto lane_off = [&](int tt) { return blk ? ((tt * KG4 + q) * B + bA) * 16 : (bA * T + tt) * K4 * 4 + q * 16; };
+    const int col_mul = blk ? 4 * B : 4;
 
     const int er = wave & 3;
     const int eb = b0 + (lane >> 4) * 4 + er, ej = j0 + (lane & 15);
@@ -1502,13 +1548,13 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_bwd_kernel(const Bwd2Pa
             if (threadIdx.x == 0) s_ok = group_wait(cnt_top, (unsigned)(NJ * (step + 1)), sticky) ? 1 : 0;
             __syncthreads();
             if (!s_ok) break;  // workgroup-uniform
-            const int off = (bA * T + t) * K4 * 4 + q * 16;
+            const int off = lane_off(t);
             if constexpr (X6) {
 #pragma unroll
                 for (int c0 = 0; c0 < CPH; c0 += CB) {
                     f32x4 a[CB];
 #pragma unroll
-                    for (int u = 0; u < CB; ++u) a[u] = ld4_sc1(dres_top, off, colb(c0 + u) * 4);
+                    for (int u = 0; u < CB; ++u) a[u] = ld4_sc1(dres_top, off, colb(c0 + u) * col_mul);
 #pragma unroll
                     for (int u = 0; u < CB; u += 4) {
                         acc0 = mfma_x6(split3(a[u], a[u + 1]), w3_lo[(c0 + u) / 2], acc0);
@@ -1518,7 +1564,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_bwd_kernel(const Bwd2Pa
             } else {
                 f32x4 a[CPH];
 #pragma unroll
-                for (int u = 0; u < CPH; ++u) a[u] = ld4_sc1(dres_top, off, colb(u) * 4);
+                for (int u = 0; u < CPH; ++u) a[u] = ld4_sc1(dres_top, off, colb(u) * col_mul);
 #pragma unroll
                 for (int u = 0; u < CPH; u += 2) {  // chunks beyond this wave's range hold zero weights: no branch
 #pragma unroll
@@ -1535,13 +1581,13 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_bwd_kernel(const Bwd2Pa
             if (threadIdx.x == 0) s_ok = group_wait(cnt_own, (unsigned)(NJ * step), sticky) ? 1 : 0;
             __syncthreads();
             if (!s_ok) break;  // workgroup-uniform
-            const int off = (bA * T + t + 1) * K4 * 4 + q * 16;
+            const int off = lane_off(t + 1);
             if constexpr (X6) {
 #pragma unroll
                 for (int c0 = 0; c0 < CPH; c0 += CB) {
                     f32x4 a[CB];
 #pragma unroll
-                    for (int u = 0; u < CB; ++u) a[u] = ld4_sc1(dres_own, off, colb(c0 + u) * 4);
+                    for (int u = 0; u < CB; ++u) a[u] = ld4_sc1(dres_own, off, colb(c0 + u) * col_mul);
 #pragma unroll
                     for (int u = 0; u < CB; u += 4) {
                         acc0 = mfma_x6(split3(a[u], a[u + 1]), w3_hi[(c0 + u) / 2], acc0);
@@ -1551,7 +1597,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_bwd_kernel(const Bwd2Pa
             } else {
                 f32x4 a[CPH];
 #pragma unroll
-                for (int u = 0; u < CPH; ++u) a[u] = ld4_sc1(dres_own, off, colb(u) * 4);
+                for (int u = 0; u < CPH; ++u) a[u] = ld4_sc1(dres_own, off, colb(u) * col_mul);
 #pragma unroll
                 for (int u = 0; u < CPH; u += 2) {
 #pragma unroll
@@ -1573,10 +1619,20 @@ __global__ __launch_bounds__(LSTM_NT) void lstm2_persist_bwd_kernel(const Bwd2Pa
             const float tc = tanhf(cout);
             const float dc = dc_reg + dh * og * (1.f - tc * tc);
             float* dg = dgo + ((long)eb * T + t) * K4;
-            st_sc1(dg + ej, dc * gg * ig * (1.f - ig));
-            st_sc1(dg + H + ej, dc * cprev * fg * (1.f - fg));
-            st_sc1(dg + 2 * H + ej, dc * ig * (1.f - gg * gg));
-            st_sc1(dg + 3 * H + ej, dh * tc * og * (1.f - og));
+            const float d0 = dc * gg * ig * (1.f - ig), d1 = dc * cprev * fg * (1.f - fg);
+            const float d2 = dc * ig * (1.f - gg * gg), d3 = dh * tc * og * (1.f - og);
+            st_sc1(dg + ej, d0);
+            st_sc1(dg + H + ej, d1);
+            st_sc1(dg + 2 * H + ej, d2);
+            st_sc1(dg + 3 * H + ej, d3);
+            if (blk) {  // k = gate * H + unit: the gates' k groups are H / 4 groups apart
+                float* xo = p.hx[layer] + ((long)(t * KG4 + (ej >> 2)) * B + eb) * 4 + (ej & 3);
+                const long gs = (long)(H / 4) * B * 4;
+                st_sc1(xo, d0);
+                st_sc1(xo + gs, d1);
+                st_sc1(xo + 2 * gs, d2);
+                st_sc1(xo + 3 * gs, d3);
+            }
             dc_reg = dc * fg;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1987,6 +2043,9 @@ extern "C" int cgn_lstm2_bwd_persistent_f32(void* stream, const cgn_lstm2_bwd* d
     p.cbuf[0] = d->cbuf0; p.gates[0] = d->gates0; p.cbuf[1] = d->cbuf1; p.gates[1] = d->gates1;
     p.dh_ext1 = d->dh_ext1; p.dh_bs = d->dh_bs; p.dh_ts = d->dh_ts;
     p.dgates[0] = d->dgates0; p.dgates[1] = d->dgates1;
+    CGN_CHECK_ARG((uintptr_t)d->handoff % 16 == 0);
+    p.hx[0] = (float*)d->handoff;
+    p.hx[1] = d->handoff ? (float*)d->handoff + (long)B * T * 4 * H : nullptr;
     p.B = B; p.T = T; p.H = H; p.flat = xcd_identity();
     hipStream_t st = (hipStream_t)stream;
     unsigned* sticky = (unsigned*)((char*)sync_ws + (sync_ws_bytes / 128 - 1) * 128);

@@ -88,7 +88,7 @@ class Lstm2Fwd(C.Structure):
 
 class Lstm2Bwd(C.Structure):
     _fields_ = [(n, c_ptr) for n in ("w_hh0", "w_ih1", "w_hh1", "cbuf0", "gates0", "cbuf1", "gates1", "dh_ext1",
-                                     "dgates0", "dgates1")] + [("dh_bs", c_i64), ("dh_ts", c_i64)]
+                                     "dgates0", "dgates1")] + [("dh_bs", c_i64), ("dh_ts", c_i64), ("handoff", c_ptr)]
 
 
 class CodeHeadFwd(C.Structure):

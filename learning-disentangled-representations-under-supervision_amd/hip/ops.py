@@ -1117,10 +1117,19 @@ def clear_lstm_sticky_timeouts():
         ws[-32:].zero_()
 
 
+# the persistent recurrences hand h_t / dgates_t over through a blocked scratch (cgn_lstm_fwd_seq.handoff: whole cache
+# lines per load); CGN_LSTM_HANDOFF=0 keeps the loads on the history buffers (A/B switch; same bits at H <= 512)
+LSTM_HANDOFF = os.environ.get("CGN_LSTM_HANDOFF", "1") != "0"
+
+
 def _lstm_handoff_wanted(H):
-    """bf16 mode with plain-bf16 recurrences (LSTM_BF16_RT == 2) at H > 512: the library wants a bf16 hand-off scratch
-    per sequence (include/cgn_hip.h cgn_lstm_fwd_seq.handoff)."""
-    return COMPUTE == _lib.COMPUTE_BF16 and int(LSTM_BF16_RT) == 2 and H > 512 and H % 256 == 0
+    """H <= 512: the fp32 scratch (any mode); H > 512: the bf16 scratch of the bf16 mode's plain-bf16 recurrences
+    (LSTM_BF16_RT == 2, H % 256 == 0). include/cgn_hip.h cgn_lstm_fwd_seq.handoff."""
+    if not LSTM_HANDOFF:
+        return False
+    if H <= 512:
+        return True
+    return COMPUTE == _lib.COMPUTE_BF16 and int(LSTM_BF16_RT) == 2 and H % 256 == 0
 
 
 _lstm_handoff = {}
@@ -1163,7 +1172,7 @@ def lstm_seq_fwd(seqs, B, T, H):
     if grp:
         if _lstm_handoff_wanted(H):
             for i in range(len(seqs)):  # bf16 hand-off scratch [2][H/8][B][8] per sequence (operand mode 2)
-                arr[i].handoff = _lstm_handoff_scratch(dev, "fwd", i, 2 * B * H).data_ptr()
+                arr[i].handoff = _lstm_handoff_scratch(dev, "fwd", i, 4 * B * H).data_ptr()  # (2*B*H*4 bytes)
         ws = _lstm_sync_ws(dev)
         for i in range(0, len(seqs), grp):
             sub = (_lib.LstmFwdSeq * grp).from_buffer(arr, i * C.sizeof(_lib.LstmFwdSeq))
@@ -1211,7 +1220,7 @@ def lstm_seq_bwd(seqs, B, T, H):
     if grp:
         if _lstm_handoff_wanted(H):
             for i in range(len(seqs)):
-                arr[i].handoff = _lstm_handoff_scratch(dev, "bwd", i, 2 * B * 4 * H).data_ptr()
+                arr[i].handoff = _lstm_handoff_scratch(dev, "bwd", i, 4 * B * 4 * H).data_ptr()
         ws = _lstm_sync_ws(dev)
         for i in range(0, len(seqs), grp):
             sub = (_lib.LstmBwdSeq * grp).from_buffer(arr, i * C.sizeof(_lib.LstmBwdSeq))
@@ -1273,6 +1282,8 @@ def lstm2_bwd(w_hh0, w_ih1, w_hh1, cbuf0, gates0, cbuf1, gates1, dh_ext1, dh_bs,
         nelem = dh_ext1.untyped_storage().nbytes() // 4 - dh_ext1.storage_offset()
         _req(dh_bs >= 0 and dh_ts >= 0 and (B - 1) * dh_bs + (T - 1) * dh_ts + H <= nelem, "dh_ext1 addressing out of range")
         d.dh_ext1, d.dh_bs, d.dh_ts = dh_ext1.data_ptr(), int(dh_bs), int(dh_ts)
+    if LSTM_HANDOFF:  # blocked copies of both layers' gate gradients (2 * B*T*4H fp32 = 4 * B*T*4H bf16-sized elements)
+        d.handoff = _lstm_handoff_scratch(dev, "bwd2", 0, 4 * B * T * 4 * H).data_ptr()
     ws = _lstm_sync_ws(dev)
     _call("cgn_lstm2_bwd_persistent_f32", dev, C.byref(d), B, T, H, _ptr(ws), ws.numel() * 4)
 

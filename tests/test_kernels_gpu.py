@@ -167,6 +167,17 @@ def test_lstm2_wavefront_fwd_bwd(dev, B, T, H, Din):
     ops.lstm2_bwd(P["weight_hh_l0"], P["weight_ih_l1"], P["weight_hh_l1"], g0.cbuf, g0.gates, g1.cbuf, g1.gates, ext,
                   T * H, H, dg0, dg1, B, T, H)
     assert ops.lstm_sticky_timeouts() == 0 and ops.lstm_counters_at_rest(dev)
+    # the blocked hand-off copies (ops.LSTM_HANDOFF) change where the workgroups read from, not one bit of the result
+    was = ops.LSTM_HANDOFF
+    ops.LSTM_HANDOFF = not was
+    try:
+        dg0b, dg1b = torch.full_like(dg0, float("nan")), torch.full_like(dg1, float("nan"))
+        ops.lstm2_bwd(P["weight_hh_l0"], P["weight_ih_l1"], P["weight_hh_l1"], g0.cbuf, g0.gates, g1.cbuf, g1.gates, ext,
+                      T * H, H, dg0b, dg1b, B, T, H)
+    finally:
+        ops.LSTM_HANDOFF = was
+    assert torch.equal(dg0, dg0b) and torch.equal(dg1, dg1b)
+    assert ops.lstm_sticky_timeouts() == 0 and ops.lstm_counters_at_rest(dev)
     h0, h0ax = g0.hout_operand()
     for l, (s_, dg, xop) in enumerate(((g0, dg0, (xd, engine.Axis(Din, 0, 0))), (g1, dg1, (h0, h0ax)))):
         G = {k: torch.full_like(P[k + "_l%d" % l], float("nan")) for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")}
@@ -442,3 +453,45 @@ def test_row_tiled_lstm_bf16_operands_in_the_bf16_mode(dev, B, T, H, bidir, init
             assert not torch.equal(a, b), name
             assert torch.isfinite(b).all(), name
             assert rel(b, a.double().cpu()) < bar, name
+
+
+@pytest.mark.parametrize("B,T,H,bidir,init", [(64, 7, 512, True, True), (40, 5, 256, False, False), (64, 6, 320, True, False)])
+def test_persistent_lstm_handoff_scratch_changes_no_bit(dev, B, T, H, bidir, init, monkeypatch):
+    """The persistent recurrences at H <= 512 read h_t / dgates_t of the other workgroups from the blocked fp32 hand-off
+    scratch (whole cache lines per load) instead of the history buffers: same values, same summation order - every
+    output equals the launch without the scratch bit for bit; zero and given initial states, both directions, an H
+    whose chunks do not fill the waves evenly."""
+    engine, ops = _mods()
+    nseq = 2 if bidir else 1
+    assert ops.lstm_persistent_group(nseq, B, T, H, dev) == nseq
+    g = torch.Generator().manual_seed(B * 3 + H + T)
+    xg = [torch.randn(B, T, 4 * H, generator=g).to(dev) for _ in range(nseq)]
+    whh = [(torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dev) for _ in range(nseq)]
+    dcs = [torch.randn(B, H, generator=g).to(dev) for _ in range(nseq)]
+    exts = [(torch.randn(B, T, H, generator=g).to(dev), T * H, H) for _ in range(nseq)]
+    h0 = [torch.randn(B, H, generator=g).to(dev) * 0.5 for _ in range(nseq)]
+    c0 = [torch.randn(B, H, generator=g).to(dev) * 0.5 for _ in range(nseq)]
+
+    def run(handoff):
+        monkeypatch.setattr(ops, "LSTM_HANDOFF", handoff)
+        seqs = []
+        for i in range(nseq):
+            s = engine.LstmSeq(B, T, H, dev, bool(i))
+            s.xg.copy_(xg[i])
+            if init:
+                s.set_initial(h0[i], c0[i])
+            else:
+                s.set_initial()
+            seqs.append(s)
+        engine.lstm_run_fwd(seqs, whh)
+        dgs = engine.lstm_run_bwd(seqs, whh, exts, [None] * nseq, [d.clone() for d in dcs])
+        torch.cuda.synchronize()
+        assert ops.lstm_sticky_timeouts() == 0 and ops.lstm_counters_at_rest(dev)
+        return [s.hbuf.clone() for s in seqs] + [s.cbuf.clone() for s in seqs] + [s.gates.clone() for s in seqs] + \
+               [d.clone() for d in dgs]
+
+    ref = run(False)
+    for _ in range(2):
+        got = run(True)
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
