@@ -794,6 +794,9 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdPara
 // 32 KB reduction buffer; hand-off, counters and timeouts are those of the kernels above (one group = the workgroups
 // that share a 16RT-row batch tile). RT = 1, H <= 512 keeps the kernels above.
 // ------------------------------------------------------------------------------------------------------------------
+// (The fp32 blocked scratch of the kernels above was tried here too and made the fp32 forms at H = 1024, B = 256 SLOWER,
+// forward 21.4 -> 24.2 and backward 34.6 -> 44.0 us per step: with 256 rows per k group a lane's successive loads are
+// 16 KB apart. These kernels keep reading the history buffers unless they run the bf16 hand-off below.)
 // XM: 0 = fp32 MFMA, 3 = X6, 2 = X3 (two-term operands), 1 = X1 (plain bf16 operands; the bf16 mode at H > 512). X1's
 // weight slice takes a quarter of the registers of the fp32 one (a bf16x8 per 8 k and gate instead of two f32x4), which
 // buys what the recurrence at H = 1024 lacks: loads in flight. Forward: the h rows of ALL row tiles of a step are

@@ -455,12 +455,15 @@ def test_row_tiled_lstm_bf16_operands_in_the_bf16_mode(dev, B, T, H, bidir, init
             assert rel(b, a.double().cpu()) < bar, name
 
 
-@pytest.mark.parametrize("B,T,H,bidir,init", [(64, 7, 512, True, True), (40, 5, 256, False, False), (64, 6, 320, True, False)])
+@pytest.mark.parametrize("B,T,H,bidir,init", [(64, 7, 512, True, True), (40, 5, 256, False, False), (64, 6, 320, True, False),
+                                               (256, 3, 512, False, True), (64, 3, 1024, False, False),
+                                               (200, 3, 1024, False, True)])
 def test_persistent_lstm_handoff_scratch_changes_no_bit(dev, B, T, H, bidir, init, monkeypatch):
     """The persistent recurrences at H <= 512 read h_t / dgates_t of the other workgroups from the blocked fp32 hand-off
     scratch (whole cache lines per load) instead of the history buffers: same values, same summation order - every
     output equals the launch without the scratch bit for bit; zero and given initial states, both directions, an H
-    whose chunks do not fill the waves evenly."""
+    whose chunks do not fill the waves evenly, and the row-tiled kernels (B = 256 at H = 512; H = 1024 with one and with
+    four row tiles, fp32 mode)."""
     engine, ops = _mods()
     nseq = 2 if bidir else 1
     assert ops.lstm_persistent_group(nseq, B, T, H, dev) == nseq
