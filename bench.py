@@ -291,8 +291,10 @@ def main():
                                        "bf16 matrix pipe as exact three-term operand splits, X6: fp32 accuracy, "
                                        "include/cgn_hip.h CGN_COMPUTE_F32X6" if ops.GEMM_X6 else "fp32 MFMA"))
                                       if args.compute == "f32" else "OPTIONAL bf16 mode (bf16 MFMA operands, fp32 "
-                                      "accumulation; logits / dlogits %s; everything else fp32 in memory; not the "
-                                      "metric's fp32 configuration)" % ("held in bf16" if ops.BF16_STORAGE else "fp32"))
+                                      "accumulation; large products on operands cast to bf16 once (bf16 x bf16 kernel: "
+                                      "%s); logits / dlogits %s; parameters, optimizer state, cell states and every "
+                                      "other activation fp32 in memory; not the metric's fp32 configuration)" % (
+                                          "on" if ops.BB_GEMM else "off", "held in bf16" if ops.BF16_STORAGE else "fp32"))
                                    + ", calc_z_loss=%s" % args.z_loss,
                        "global_batch": world * BATCH, "seq_len": SEQ, "parallelism": "dp%d" % world,
                        "launch": launch},

@@ -8,7 +8,13 @@ rm -rf "$O" && mkdir -p "$O/trace" "$O/fetch" "$O/write" "$O/mfma"
 cd "$R" && timeout -k 10 300 python3 bench.py --gemm-table "$O/gemm_table.txt" > "$O/bench_line.json" 2> "$O/bench.err" || { tail "$O/bench.err"; exit 1; }
 timeout -k 10 200 python3 bench.py --no-cpu-baseline --compute bf16 --gemm-table "$O/gemm_table_bf16.txt" > "$O/bench_line_bf16.json" 2>> "$O/bench.err" || { tail "$O/bench.err"; exit 1; }
 timeout -k 10 300 python3 bench.py --no-cpu-baseline --workload cfg4 --steps 10 > "$O/bench_line_cfg4.json" 2>> "$O/bench.err" || { tail "$O/bench.err"; exit 1; }
-timeout -k 10 300 python3 bench.py --no-cpu-baseline --workload cfg4 --compute bf16 --steps 10 > "$O/bench_line_cfg4_bf16.json" 2>> "$O/bench.err" || { tail "$O/bench.err"; exit 1; }
+timeout -k 10 300 python3 bench.py --no-cpu-baseline --workload cfg4 --compute bf16 --steps 10 --gemm-table "$O/gemm_table_cfg4_bf16.txt" > "$O/bench_line_cfg4_bf16.json" 2>> "$O/bench.err" || { tail "$O/bench.err"; exit 1; }
+# the recurrences alone: cfg2 shapes (with and without the blocked hand-off scratch), configs[3] shapes in the three operand modes
+{ echo "# tools/lstm_bench.py 64 512 20"; timeout -k 10 120 python3 tools/lstm_bench.py 64 512 20; echo "# CGN_LSTM_HANDOFF=0"; CGN_LSTM_HANDOFF=0 timeout -k 10 120 python3 tools/lstm_bench.py 64 512 20;
+  echo "# tools/lstm_bench.py 256 1024 40 (fp32 mode)"; timeout -k 10 120 python3 tools/lstm_bench.py 256 1024 40;
+  echo "# CGN_COMPUTE=bf16 CGN_LSTM_BF16_RT=1 (two-term operands)"; CGN_COMPUTE=bf16 CGN_LSTM_BF16_RT=1 timeout -k 10 120 python3 tools/lstm_bench.py 256 1024 40;
+  echo "# CGN_COMPUTE=bf16 (plain bf16 operands, bf16 hand-off scratch)"; CGN_COMPUTE=bf16 timeout -k 10 120 python3 tools/lstm_bench.py 256 1024 40; } > "$O/lstm_bench.txt" 2>> "$O/bench.err" || { tail "$O/bench.err"; exit 1; }
+timeout -k 10 400 python3 tools/gemm_bb_probe.py "$O/bb_probe.txt" > /dev/null 2>> "$O/bench.err" || { tail "$O/bench.err"; exit 1; }
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d "$O/trace" -o t -- python3 "$R/bench.py" --no-cpu-baseline > "$O/trace.log" 2>&1 || { echo "kernel trace failed"; tail -5 "$O/trace.log"; exit 1; }
 DB=$(ls "$O"/trace/*.db "$O"/trace/*/*.db 2>/dev/null | head -1)

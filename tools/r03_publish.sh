@@ -2,7 +2,7 @@
 # copies the round-3 summaries from gpurun_out/ (scratch) into profiles/ (tracked)
 cd "$(dirname "$0")/.."
 P=gpurun_out/r03_prof
-for f in kernel_stats.csv step_timeline.txt pmc_traffic.json pmc_traffic.txt mfma_busy.txt gemm_table.txt gemm_table_bf16.txt; do
+for f in kernel_stats.csv step_timeline.txt pmc_traffic.json pmc_traffic.txt mfma_busy.txt gemm_table.txt gemm_table_bf16.txt gemm_table_cfg4_bf16.txt lstm_bench.txt bb_probe.txt; do
   [ -f $P/$f ] && cp $P/$f profiles/r03_$f
 done
 for f in bench_line bench_line_bf16 bench_line_cfg4 bench_line_cfg4_bf16; do
