@@ -569,7 +569,7 @@ typedef struct cgn_gemm_bb_desc {
     float alpha, beta;
     int32_t c_bf16;
     int32_t force_tile;   /* 0 = heuristic; 256 = 256x256 block tile, 192 = 256x128, 128 = 128x128 */
-    int32_t force_splitk; /* 0 = heuristic */
+    int32_t force_splitk; /* 0 = heuristic, else 1..16 */
     /* The two logits-sized products of model/cgn.py:1103-1108 with the logits HELD in bf16, as cgn_gemm_desc has them:
      * a_transform CGN_ATRANS_EXP: A (bf16 logits) enters the product as exp(A * a_scale - a_row_param[m]) - the soft
      *   embedding softmax(logits / tau) @ E with the probabilities formed as the tiles are staged;

@@ -662,7 +662,7 @@ extern "C" int cgn_gemm_bb(void* stream, const cgn_gemm_bb_desc* d, void* ev_sta
     CGN_CHECK_ARG(d->lda % 8 == 0 && d->ldb % 8 == 0 && d->lda >= d->K && d->ldb >= d->K && d->ldc >= d->N);
     CGN_CHECK_ARG((uintptr_t)d->A % 16 == 0 && (uintptr_t)d->B % 16 == 0 && (uintptr_t)d->workspace % 16 == 0);
     CGN_CHECK_ARG(d->force_tile == 0 || d->force_tile == 128 || d->force_tile == 192 || d->force_tile == 256);
-    CGN_CHECK_ARG(d->force_splitk >= 0 && d->force_splitk <= 64);
+    CGN_CHECK_ARG(d->force_splitk >= 0 && d->force_splitk <= 16);
     CGN_CHECK_ARG(d->a_transform == CGN_ATRANS_NONE || (d->a_transform == CGN_ATRANS_EXP && d->a_row_param));
     CGN_CHECK_ARG(d->epilogue == CGN_EPI_LINEAR || d->epilogue == CGN_EPI_SOFTMAX_BWD);
     const bool smb = d->epilogue == CGN_EPI_SOFTMAX_BWD, expa = d->a_transform == CGN_ATRANS_EXP;
