@@ -201,11 +201,12 @@ typedef struct cgn_lstm_fwd_seq {
     float* gates;
     int32_t reverse;
     int32_t init_zero; /* 1: zero initial state (nn.LSTM called without (h0,c0)); the library zeroes the initial slots */
-    /* nullable, persistent entry points only: scratch of 2*B*H*4 bytes (16-byte aligned) through which the workgroups
-     * hand h_t to each other, blocked by k group so that a wave's load covers whole cache lines: fp32 in the kernels for
-     * H <= 512 (same values and summation order as without it: results do not change by a bit; the recurrence's loads
-     * take half the L2 requests), bf16 in operand mode 2 at H > 512 (cgn_lstm_set_operand_mode). Contents need not
-     * survive the call; launches that run at the same time need scratches of their own. */
+    /* nullable, persistent entry points only: scratch of 2*B16*H*4 bytes (B16 = B rounded up to 16; 16-byte aligned)
+     * through which the workgroups hand h_t to each other, blocked by k group so that a wave's load covers whole cache
+     * lines: fp32 in every fp32-accurate kernel (same values and summation order as without it: results do not change
+     * by a bit; the recurrence's loads take half the L2 requests), bf16 in operand mode 2 at H > 512
+     * (cgn_lstm_set_operand_mode). Contents need not survive the call; launches that run at the same time need
+     * scratches of their own. */
     void* handoff;
 } cgn_lstm_fwd_seq;
 
@@ -276,7 +277,7 @@ typedef struct cgn_lstm_bwd_seq {
     float* dc_state;
     int64_t dh_bs, dh_ts;
     int32_t reverse;
-    void* handoff; /* nullable, persistent entry point only: scratch of 2*B*4H*4 bytes for dgates_t, as cgn_lstm_fwd_seq.handoff */
+    void* handoff; /* nullable, persistent entry point only: scratch of 2*B16*4H*4 bytes for dgates_t, as cgn_lstm_fwd_seq.handoff */
 } cgn_lstm_bwd_seq;
 
 int cgn_lstm_seq_bwd_f32(void* stream, const cgn_lstm_bwd_seq* seqs /* host */, int32_t nseq, int32_t B, int32_t T,

@@ -382,6 +382,12 @@ __device__ __forceinline__ void st_sc1(unsigned* p, unsigned v) {
 __device__ __forceinline__ long hx_off(int par, int KG, int kg, int B, int b) {  // element offset of (parity, k group, row)
     return ((long)(par * KG + kg) * B + b) * 8;
 }
+// element offset of row b, k group kg (4 fp32) in the TILE-major fp32 scratch of the row-tiled kernels:
+// [parity][batch tile of 16 rows][KG4][16 rows][4] - with B = 256 rows the k groups of the layout above lie 4 KB apart
+// and a lane's successive loads 16 KB; here a wave's load is 1 KB of contiguous memory whatever B is
+__device__ __forceinline__ long hx32_off(int par, int NBT, int KG4, int b, int kg) {
+    return ((((long)par * NBT + (b >> 4)) * KG4 + kg) * 16 + (b & 15)) * 4;
+}
 __device__ __forceinline__ unsigned pack_bf16x2_lstm(float a, float b) {
     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
     bf16x2_t v;
@@ -796,9 +802,10 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_kernel(const BwdPara
 // 32 KB reduction buffer; hand-off, counters and timeouts are those of the kernels above (one group = the workgroups
 // that share a 16RT-row batch tile). RT = 1, H <= 512 keeps the kernels above.
 // ------------------------------------------------------------------------------------------------------------------
-// (The fp32 blocked scratch of the kernels above was tried here too and made the fp32 forms at H = 1024, B = 256 SLOWER,
+// (The fp32 scratch layout of the kernels above, [parity][k / 4][B][4], made the fp32 forms at H = 1024, B = 256 SLOWER,
 // forward 21.4 -> 24.2 and backward 34.6 -> 44.0 us per step: with 256 rows per k group a lane's successive loads are
-// 16 KB apart. These kernels keep reading the history buffers unless they run the bf16 hand-off below.)
+// 16 KB apart. The row-tiled kernels use the tile-major layout of hx32_off instead: backward 33.9 -> 28.5 us per step at
+// H = 1024, 10.1 -> 9.5 at H = 512, B = 256; the forward launches do not move.)
 // XM: 0 = fp32 MFMA, 3 = X6, 2 = X3 (two-term operands), 1 = X1 (plain bf16 operands; the bf16 mode at H > 512). X1's
 // weight slice takes a quarter of the registers of the fp32 one (a bf16x8 per 8 k and gate instead of two f32x4), which
 // buys what the recurrence at H = 1024 lacks: loads in flight. Forward: the h rows of ALL row tiles of a step are
@@ -868,8 +875,12 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdP
     const __amdgpu_buffer_rsrc_t hres =
         __builtin_amdgcn_make_buffer_rsrc((void*)sq.hbuf, 0, B * (T + 1) * H * 4, 0x00020000);
     const int KG = H / 8;  // X1: k groups of the hand-off scratch [2][KG][B][8] bf16
-    const __amdgpu_buffer_rsrc_t xres =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(XM == 1 ? (void*)sq.hx : (void*)sq.hbuf), 0, 2 * KG * B * 16, 0x00020000);
+    // the other forms: an fp32 scratch (nullable; the same bits with and without), TILE-major here,
+    // [parity][batch tile of 16 rows][H / 4][16][4]: a wave's load is 1 KB of contiguous memory (hx32_off)
+    float* hx32 = XM == 1 ? nullptr : reinterpret_cast<float*>(sq.hx);
+    const int KG4 = H / 4, NBT = (B + 15) / 16;
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(sq.hx ? (void*)sq.hx : (void*)sq.hbuf), 0, XM == 1 ? 2 * KG * B * 16 : 2 * NBT * KG4 * 256, 0x00020000);
 
     // cell-update elements of this thread (waves 0..3): row (lane>>4)*4 + wave of EVERY row tile, unit lane&15
     const int er = wave & 3;
@@ -922,6 +933,11 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdP
                     const int pu = (2 * u < cpw && c_beg + 2 * u < nchunks) ? u : 0;
                     a[buf][u] = ld4_sc1(xres, xoff + pu * (4 * B * 16));
                 }
+            } else if (hx32 && step > 0) {  // (uniform; step 0 reads the given initial state from the history buffer)
+                // k group kc / 4 sits kc / 4 * 256 = koff * 16 bytes into the row's tile
+                const int xoff = (int)hx32_off((step + 1) & 1, NBT, KG4, min(b0 + rt * 16 + fr, B - 1), 0) * 4;
+#pragma unroll
+                for (int u = 0; u < CPW; ++u) a[buf][u] = ld4_sc1(xres, xoff + koff[u] * 16);
             } else {
                 const int hoff = (min(b0 + rt * 16 + fr, B - 1) * (T + 1) + slot_prev) * H * 4;
 #pragma unroll
@@ -1000,6 +1016,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdP
                 sq.cbuf[((long)eb * (T + 1) + slot_out) * H + ej] = cn;
                 st_sc1(sq.hbuf + ((long)eb * (T + 1) + slot_out) * H + ej, hn);
                 if constexpr (XM == 1) hx_store_pair(sq.hx, hx_off(step & 1, KG, ej >> 3, B, eb) + (ej & 7), hn, lane);
+                else if (hx32) st_sc1(hx32 + hx32_off(step & 1, NBT, KG4, eb, ej >> 2) + (ej & 3), hn);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the arrival is signalled
@@ -1068,8 +1085,10 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_rt_kernel(const BwdP
     }
     const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void*)sq.dgates, 0, B * T * K * 4, 0x00020000);
     const int KG = K / 8;  // X1: k groups of the hand-off scratch [2][KG][B][8] bf16
-    const __amdgpu_buffer_rsrc_t xres =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(XM == 1 ? (void*)sq.hx : (void*)sq.dgates), 0, 2 * KG * B * 16, 0x00020000);
+    float* hx32 = XM == 1 ? nullptr : reinterpret_cast<float*>(sq.hx);  // the other forms: tile-major fp32 scratch (hx32_off)
+    const int KG4 = K / 4, NBT = (B + 15) / 16;
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(sq.hx ? (void*)sq.hx : (void*)sq.dgates), 0, XM == 1 ? 2 * KG * B * 16 : 2 * NBT * KG4 * 256, 0x00020000);
 
     const int er = wave & 3;
     const int ej = j0 + (lane & 15);
@@ -1105,11 +1124,13 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_rt_kernel(const BwdP
                 return;
             }
             const int aoff = (min(b0 + rt * 16 + fr, B - 1) * T + t_next) * K * 4 + kbase;
+            // tile-major scratch: k group (c_beg + cu) * 4 + q of the row, 256 bytes per k group
+            const int xoff = (int)hx32_off((step + 1) & 1, NBT, KG4, min(b0 + rt * 16 + fr, B - 1), c_beg * 4 + q) * 4;
 #pragma unroll
             for (int u = 0; u < CB; ++u) {
                 // chunks beyond this wave's range hold zero weights; their (clamped) loads re-read chunk 0
                 const int cu = (bi * CB + u < cpw && c_beg + bi * CB + u < nchunks) ? (bi * CB + u) : 0;
-                ab[buf][u] = ld4_sc1(dres, aoff + cu * 64);
+                ab[buf][u] = hx32 ? ld4_sc1(xres, xoff + cu * 1024) : ld4_sc1(dres, aoff + cu * 64);
             }
         };
         if constexpr (PIPE) {
@@ -1196,6 +1217,13 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_rt_kernel(const BwdP
                     hx_store_pair(sq.hx, xo + gs, d1, lane);
                     hx_store_pair(sq.hx, xo + 2 * gs, d2, lane);
                     hx_store_pair(sq.hx, xo + 3 * gs, d3, lane);
+                } else if (hx32) {
+                    float* xo = hx32 + hx32_off(step & 1, NBT, KG4, eb, ej >> 2) + (ej & 3);
+                    const long gs = (long)H * 16;  // H / 4 k groups of 16 rows x 4 values between the gates
+                    st_sc1(xo, d0);
+                    st_sc1(xo + gs, d1);
+                    st_sc1(xo + 2 * gs, d2);
+                    st_sc1(xo + 3 * gs, d3);
                 }
                 dc_reg[rt] = dc * fg;
             }

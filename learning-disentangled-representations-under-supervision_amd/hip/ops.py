@@ -336,6 +336,10 @@ def pad8(n):
     return (n + 7) // 8 * 8
 
 
+def pad16(n):
+    return (n + 15) // 16 * 16
+
+
 # While a bb_memo() block is open, ops.gemm's bf16 copies of fp32 operands are kept and served again to later products
 # of the block that name the same operand (same base, axes, extents). The caller promises that the operands are not
 # written inside the block.
@@ -1123,13 +1127,9 @@ LSTM_HANDOFF = os.environ.get("CGN_LSTM_HANDOFF", "1") != "0"
 
 
 def _lstm_handoff_wanted(H):
-    """H <= 512: the fp32 scratch (any mode); H > 512: the bf16 scratch of the bf16 mode's plain-bf16 recurrences
-    (LSTM_BF16_RT == 2, H % 256 == 0). include/cgn_hip.h cgn_lstm_fwd_seq.handoff."""
-    if not LSTM_HANDOFF:
-        return False
-    if H <= 512:
-        return True
-    return COMPUTE == _lib.COMPUTE_BF16 and int(LSTM_BF16_RT) == 2 and H % 256 == 0
+    """Every persistent launch brings a scratch (include/cgn_hip.h cgn_lstm_fwd_seq.handoff): the library holds fp32 in
+    it, or bf16 in the bf16 mode's plain-bf16 recurrences at H > 512 (LSTM_BF16_RT == 2, H % 256 == 0)."""
+    return LSTM_HANDOFF
 
 
 _lstm_handoff = {}
@@ -1172,7 +1172,7 @@ def lstm_seq_fwd(seqs, B, T, H):
     if grp:
         if _lstm_handoff_wanted(H):
             for i in range(len(seqs)):  # bf16 hand-off scratch [2][H/8][B][8] per sequence (operand mode 2)
-                arr[i].handoff = _lstm_handoff_scratch(dev, "fwd", i, 4 * B * H).data_ptr()  # (2*B*H*4 bytes)
+                arr[i].handoff = _lstm_handoff_scratch(dev, "fwd", i, 4 * pad16(B) * H).data_ptr()  # (2*B16*H*4 bytes)
         ws = _lstm_sync_ws(dev)
         for i in range(0, len(seqs), grp):
             sub = (_lib.LstmFwdSeq * grp).from_buffer(arr, i * C.sizeof(_lib.LstmFwdSeq))
@@ -1220,7 +1220,7 @@ def lstm_seq_bwd(seqs, B, T, H):
     if grp:
         if _lstm_handoff_wanted(H):
             for i in range(len(seqs)):
-                arr[i].handoff = _lstm_handoff_scratch(dev, "bwd", i, 4 * B * 4 * H).data_ptr()
+                arr[i].handoff = _lstm_handoff_scratch(dev, "bwd", i, 4 * pad16(B) * 4 * H).data_ptr()
         ws = _lstm_sync_ws(dev)
         for i in range(0, len(seqs), grp):
             sub = (_lib.LstmBwdSeq * grp).from_buffer(arr, i * C.sizeof(_lib.LstmBwdSeq))
