@@ -1684,8 +1684,11 @@ int g_num_cus[16] = {0};
 // measured at cfg2 (tools/lstm_bench.py, profiles/r03_lstm_bench.txt) forward 5.1 -> 4.5 us per step, two-layer forward
 // 7.5 -> 6.7; backward 6.0 -> 6.4 and 9.7 -> 11.5: a backward step hands over 4x the values (dgates, K = 4H), every
 // consumer wave splits its share again (64 values per lane and step: ~1 us of VALU work on a SIMD that two waves
-// share), which eats the MFMA time saved. (Splitting once at the producer and handing the bf16 parts over is the
-// next step.) CGN_LSTM_X6=0 / CGN_LSTM_X6_BWD=1 override (A/B measurements).
+// share), which eats the MFMA time saved. Splitting once at the producer and handing the three bf16 parts over through
+// a blocked scratch (6 bytes per value, three 16-byte loads per chunk pair that ARE the MFMA operands) was built and
+// measured too: encoder backward 104.5 -> 122.3 us, one generator layer 96.6 -> 116.5 - a backward step is paced by
+// the hand-off loads, not by the matrix pipe, and that form loads 1.5x the bytes. The backward kernels stay on the fp32
+// MFMA with the fp32 scratch. CGN_LSTM_X6=0 / CGN_LSTM_X6_BWD=1 override (A/B measurements).
 // 0 = every recurrence at fp32 accuracy (default); the optional bf16 mode: the row-tiled recurrences at H > 512 take
 // two-term (1) or plain (2) bf16 operands (cgn_lstm_set_operand_mode, include/cgn_hip.h)
 int g_lstm_operand_mode = 0;
