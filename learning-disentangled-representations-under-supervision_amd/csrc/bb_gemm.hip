@@ -7,7 +7,9 @@
 // Here:
 //   * block tile 256x256, 8 waves in a 2x4 grid, each wave 128x64 = 4x2 accumulators of 32x32 (128 accumulator
 //     registers): 6 fragment reads per 8 MFMAs, 48 KB of LDS reads + 16 KB of writes per 512 MFMA cycles per SIMD;
-//     a 128x128 variant (4 waves of 64x64, up to 3 blocks per CU) for products with few tiles;
+//     from the same template a 256x128 tile (4 waves of 128x64, two blocks per CU) and a 128x128 tile (4 waves of
+//     64x64, three blocks per CU) for products with few tiles or narrow outputs (the planner scores tile x split by
+//     fill, padding and the tile's measured rate);
 //   * operands are bf16 in memory, k-contiguous: a thread's 16-byte global load IS 8 consecutive k of one row and goes
 //     to LDS as one ds_write_b128, nothing is converted in the loop;
 //   * LDS image per operand and stage: [rows][32 k] bf16 = 64-byte rows WITHOUT padding, the 16-byte chunk c of row r
@@ -20,7 +22,11 @@
 //     past the last one are loads from an out-of-range offset (return 0): no masks, no branches in the loop;
 //   * blocks of one XCD (blockIdx % 8) walk 8-tile-tall column groups: an XCD's 32 resident blocks share 8 + 4 operand
 //     panels through its L2;
-//   * few-tile / tall-K products are split along K into fp32 slabs and summed in fixed order (bitwise reproducible).
+//   * few-tile / tall-K products are split along K into fp32 slabs and summed in fixed order (bitwise reproducible);
+//   * two variants for the logits-sized products over bf16 logits: an exp transform between A's global load and its LDS
+//     write (the soft embedding), and the fused softmax / CE backward epilogue, done on row chunks (see there).
+// Measured (tools/gemm_bb_probe.py, profiles/r03_bb_probe.txt): 1.09 PFLOP/s at 4096^3, 1.16 at 8192^3 - the chip's power
+// limit for this pipe (0.62 matrix-pipe busy x 1.82 GHz; tools/r03_bb_pmc.sh) -, 0.82-0.92 on the configs[3] products.
 #include "common.h"
 
 namespace cgn_bb {
