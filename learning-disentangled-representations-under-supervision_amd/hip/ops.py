@@ -445,7 +445,9 @@ def _bb_operand(t, row_ax, k_ax, rows, K, is16):
     """The bf16 [rows, pad8(K)] k-contiguous form of a GEMM operand given by its row axis and K axis, or None when the
     addressing is not one the cast kernels take."""
     if is16:
-        return t if (k_ax.stride == 1 and k_ax.rpg == 0 and row_ax.rpg == 0 and t.dim() == 2) else None
+        ok = (k_ax.stride == 1 and k_ax.rpg == 0 and row_ax.rpg == 0 and t.dim() == 2 and t.shape[0] == rows
+              and t.stride(0) == row_ax.stride and t.shape[1] >= K)
+        return t if ok else None
     kc = k_ax.stride == 1 and k_ax.rpg == 0  # k-contiguous: rows along the row axis
     if not kc and not (row_ax.stride == 1 and row_ax.rpg == 0):
         return None
@@ -485,6 +487,8 @@ def _gemm_bb_route(a, b, out, M, N, K, a_m, a_k, b_k, b_n, alpha, beta, bias0, b
     if (not a16 and not ok(a_m, a_k)) or not ok(b_n, b_k):
         return False
     A = _bb_operand(a, a_m, a_k, M, K, a16)
+    if A is None:
+        return False
     B = _bb_operand(b, b_n, b_k, N, K, False)
     Kp = pad8(K)
     gemm_bb(A if a16 else A[:M], B[:N], out, K=Kp if not a16 else K, alpha=alpha, beta=beta, bias0=bias0, bias1=bias1,
