@@ -222,7 +222,12 @@ def _step_parity(dev, name, B, calc_z, TOL):
     from ldrs_amd.hip import ops as _ops
     rep = Report("%s_B%d_%s%s" % (name, B, "z" if calc_z else "noz",
                                   ("_bf16" if _ops.BF16_STORAGE else "_bf16_fp32storage") if bf16 else ""))
-    ocfg, oracle, cfg, model = build(name, dev)
+    # CGN_PARITY_SEED=n (sweeps: other initial weights, batches and dropout masks; the default run is seed 0)
+    import os
+    SEED = int(os.environ.get("CGN_PARITY_SEED", "0"))
+    if SEED:
+        rep.case += "_seed%d" % SEED
+    ocfg, oracle, cfg, model = build(name, dev, seed=SEED)
     L = ocfg.max_seq_len - 1
     F_ = len(ocfg.sentiment_kernel_size) * ocfg.sentiment_kernel_num
     opts = O.make_optimizers(oracle)
@@ -234,8 +239,8 @@ def _step_parity(dev, name, B, calc_z, TOL):
     # stated for (identical weights); after a step the two paths' weights differ by Adam's sign-like first updates
     # (+-lr wherever a tiny gradient element changes sign), and later gradients are no longer taken at the same point
     for step in range(1 if (name.startswith("cfg") or bf16) else 3):
-        data = O.synthetic_batch(ocfg, B, L, seed=100 + step)
-        g = torch.Generator().manual_seed(7 + step)
+        data = O.synthetic_batch(ocfg, B, L, seed=100 + step + 1000 * SEED)
+        g = torch.Generator().manual_seed(7 + step + 1000 * SEED)
         masks = dict(labelled=(torch.rand(B, F_, generator=g) < 0.7).double() / 0.7,
                      generated=(torch.rand(B, F_, generator=g) < 0.7).double() / 0.7,
                      gen_drop=(torch.rand(B, L + 1, ocfg.word_embed_size, generator=g) < 0.7).double() / 0.7)
@@ -296,8 +301,18 @@ def _step_parity(dev, name, B, calc_z, TOL):
             else:
                 # Adam's first updates are sign-like (+-lr wherever |g| >> eps), so the UPDATE amplifies the gradient
                 # error of elements near zero; the weights themselves are held to 1e-6
+                wh, wo = after_h[n].detach().cpu().double(), after_o[n].detach()
+                if SEED and step == 0:
+                    # seed sweeps: a first update is lr * g / (|g| + eps); where |g| is within ~100 eps of zero it is
+                    # ill-conditioned in g (one such bias element in 100 breaks the bar at some seeds while its gradient
+                    # agrees to 1e-7), so the sweep compares updates and weights on the saturated elements only
+                    sat = upd_o.abs() >= 0.99 * upd_o.abs().max()
+                    if not bool(sat.all()):
+                        rep.note("%s: %d of %d elements with |g| < 100 eps left out of update / weight" %
+                                 (n, int((~sat).sum()), sat.numel()))
+                    upd_h, upd_o, wh, wo = upd_h[sat], upd_o[sat], wh[sat], wo[sat]
                 rep.add("update", n, step, rel(upd_h, upd_o), 0.5 if bf16 else max(2e-3, 10 * GTOL))
-                rep.add("weight", n, step, rel(after_h[n], after_o[n]), 1e-3 if bf16 else 1e-6)
+                rep.add("weight", n, step, rel(wh, wo), 1e-3 if bf16 else 1e-6)
     rep.finish()
 
 
