@@ -59,6 +59,7 @@ struct Params {
     const int64_t* ep_target;
     void* ct;
     long ep_ld, ldct;
+    int map_whole;  // block -> (split, tile) run over the whole list (few tiles per split), see bb_kernel
     int ct_vec;
     float a_scale, ep_inv_tau, ep_ce_scale;
 };
@@ -100,11 +101,30 @@ __global__ __launch_bounds__(64 * WVM * WVN, (WTM == 2 ? 3 : 2)) void bb_kernel(
     const int fr = lane & 31, fk = lane >> 5;
 
     // block -> tile: XCD x (= blockIdx % 8) owns a contiguous run of logical ids; logical ids walk groups of GM tile rows
-    int tm, tn;
+    // Split launches (splits on blockIdx.y): blockIdx.x % 8 is the XCD of a block of split 0 only - the hardware deals
+    // blocks in linear order, x fastest. Products with FEW tiles per split (<= 100: map_whole) take their run over the
+    // whole (split, tile) list in that linear order, so that an XCD works on ONE K range and its blocks share that
+    // range's operand panels: dH1 at configs[1] 66.5 -> 58 us, the highway dW at configs[3] shapes 77 -> 69, the LSTM dW
+    // 102 -> 99. Products with many tiles per split keep the per-split run although the PMC passes show their big
+    // operand fetched 1.6-3.7 times (tools/r03_cfg4_pmc.sh): with the whole-list run the soft embedding at configs[3]
+    // shapes took 756 -> 803 us and dH1 1319 -> 1382 - the re-reads of XCDs that walk the same K range at the same time
+    // are served by the memory-side cache, and that lockstep is worth more than the fetches it costs.
+    int tm, tn, split;
     {
-        const int nb = gridDim.x, per = nb >> 3, rem = nb & 7;
-        const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
-        const int l = x * per + (x < rem ? x : rem) + q;
+        int l;
+        if (p.map_whole) {
+            const int nb = gridDim.x * gridDim.y, per = nb >> 3, rem = nb & 7;
+            const int bid = blockIdx.x + gridDim.x * blockIdx.y;
+            const int x = bid & 7, q = bid >> 3;
+            const int lw = x * per + (x < rem ? x : rem) + q;
+            split = lw / (int)gridDim.x;
+            l = lw - split * (int)gridDim.x;
+        } else {
+            const int nb = gridDim.x, per = nb >> 3, rem = nb & 7;
+            const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+            l = x * per + (x < rem ? x : rem) + q;
+            split = blockIdx.y;
+        }
         constexpr int GM = 8;
         const int span = GM * p.tiles_n;
         const int g = l / span, in = l - g * span;
@@ -114,7 +134,6 @@ __global__ __launch_bounds__(64 * WVM * WVN, (WTM == 2 ? 3 : 2)) void bb_kernel(
         tn = in / gsz;
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    const int split = blockIdx.y;
     const int kbeg = split * p.kps;
     const int kend = p.K < kbeg + p.kps ? p.K : kbeg + p.kps;
     const int nk = (kend - kbeg + BK - 1) / BK;
@@ -693,6 +712,7 @@ extern "C" int cgn_gemm_bb(void* stream, const cgn_gemm_bb_desc* d, void* ev_sta
     p.M = d->M; p.N = d->N; p.K = d->K;
     p.kps = kps; p.splitk = sk;
     p.tiles_m = cgn_cdiv(d->M, t.bm); p.tiles_n = cgn_cdiv(d->N, t.bn);
+    p.map_whole = (sk > 1 && p.tiles_m * p.tiles_n <= 100) ? 1 : 0;
     p.alpha = d->alpha; p.beta = d->beta;
     p.c16 = d->c_bf16 ? 1 : 0;
     p.c_vec = (d->c_bf16 && d->ldc % 8 == 0 && (uintptr_t)d->C % 16 == 0) ? 1 : 0;
