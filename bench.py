@@ -106,7 +106,7 @@ def gemm_symbol(sym):
     """Kernel symbol of a product from ops.GEMM_PROFILE's key (csrc/gemm_core.h gemm_kernel's template arguments)."""
     if sym[0] == "bb":  # the bf16 x bf16 kernel (csrc/bb_gemm.hip): 256x256 tile with 8 waves, or 128x128 with 4
         b = lambda v: "true" if v else "false"  # noqa: E731
-        waves = {256: "4, 2, 2, 4", 192: "4, 2, 2, 2", 128: "2, 2, 2, 2"}[sym[1]]
+        waves = {256: "4, 2, 2, 4", 192: "4, 2, 2, 2", 128: "2, 2, 2, 2", 384: "2, 3, 2, 4"}[sym[1]]
         return "cgn_bb::bb_kernel<%s, %s, %s>" % (waves, b(sym[3]), b(sym[4]))
     bt, a_kc, b_kc, vec, exp, smb, bf16 = sym
     b = lambda v: "true" if v else "false"  # noqa: E731

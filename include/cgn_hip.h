@@ -569,7 +569,8 @@ typedef struct cgn_gemm_bb_desc {
     int32_t M, N, K;
     float alpha, beta;
     int32_t c_bf16;
-    int32_t force_tile;   /* 0 = heuristic; 256 = 256x256 block tile, 192 = 256x128, 128 = 128x128 */
+    int32_t force_tile;   /* 0 = heuristic; 256 = 256x256 block tile, 192 = 256x128, 128 = 128x128, 384 = 128x384 (fp32 C,
+                           * N <= 384: one column tile; the heuristic takes it for CGN_ATRANS_EXP products that fit) */
     int32_t force_splitk; /* 0 = heuristic, else 1..16 */
     /* The two logits-sized products of model/cgn.py:1103-1108 with the logits HELD in bf16, as cgn_gemm_desc has them:
      * a_transform CGN_ATRANS_EXP: A (bf16 logits) enters the product as exp(A * a_scale - a_row_param[m]) - the soft

@@ -85,13 +85,15 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 // Waves per SIMD the variants are built for (register budget 512 / waves): 256x256 = one block of 8 waves per CU;
 // 256x128 = two blocks of 4 waves (one block's epilogue runs beside the other's K loop); 128x128 = three blocks.
 template <int WTM, int WTN, int WVM, int WVN, bool EXPA = false, bool SMB = false>
-__global__ __launch_bounds__(64 * WVM * WVN, (WTM == 2 ? 3 : 2)) void bb_kernel(const Params p) {
+__global__ __launch_bounds__(64 * WVM * WVN, (WTM == 2 && WVM * WVN == 4 ? 3 : 2)) void bb_kernel(const Params p) {
     constexpr int BM = WVM * WTM * 32, BN = WVN * WTN * 32, NTH = 64 * WVM * WVN;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
     constexpr int LA = BM * 4 / NTH, LB = BN * 4 / NTH;  // 16-byte chunks per thread and tile
     constexpr int RSTEP = NTH / 4;                       // rows between a thread's chunks
     static_assert(BM * 4 % NTH == 0 && BN * 4 % NTH == 0 && RSTEP % 16 == 0, "loader geometry");
-    static_assert(WTN == 2 && WTM % 2 == 0, "the staged bf16 epilogue flushes 64 rows x 64 columns per wave");
+    // the staged bf16 epilogues flush 64 rows x 64 columns per wave; the 128x384 tile (wave tile 64x96) writes fp32 only
+    constexpr bool C16OK = WTN == 2 && WTM % 2 == 0;
+    static_assert(C16OK || !SMB, "the fused epilogue writes bf16");
     // (the fused epilogue's wave-local images, 13312 bytes per wave, outgrow the three stages of the 256x256 tile)
     constexpr int EPI_BYTES = SMB ? (NTH / 64) * (32 * 68 * 4 + 32 * 72 * 2) : 0;
     __shared__ __attribute__((aligned(16))) unsigned char lds[NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES];
@@ -454,6 +456,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, (WTM == 2 ? 3 : 2)) void bb_kernel(
             }
         return;
     }
+    if constexpr (C16OK) {
     // bf16 C: 64 rows x 64 columns of the wave at a time through LDS (free after the loop), out as 16-byte row stores
     constexpr int RS = 72;  // staging row stride in elements (144 bytes)
     static_assert((NTH / 64) * 64 * RS * 2 <= NS * STAGE, "staging images must fit the operand stages");
@@ -494,6 +497,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, (WTM == 2 ? 3 : 2)) void bb_kernel(
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    }  // C16OK
 }
 
 // Sums the slabs in fixed order and applies the linear epilogue (fp32 C only).
@@ -619,11 +623,16 @@ struct Tile {
     int code, bm, bn, slots;  // slots: blocks resident on 256 CUs (registers and LDS of the variant)
     double rate;              // steady-state rate relative to the 256x256 tile (measured at 4096^3 ... 8192^3)
 };
-// code = cgn_gemm_bb_desc.force_tile: 256 -> 256x256 (8 waves), 192 -> 256x128 (4 waves of 128x64), 128 -> 128x128
-constexpr Tile TILES[3] = {{256, 256, 256, 256, 1.0}, {192, 256, 128, 512, 0.93}, {128, 128, 128, 768, 0.80}};
+// code = cgn_gemm_bb_desc.force_tile: 256 -> 256x256 (8 waves), 192 -> 256x128 (4 waves of 128x64), 128 -> 128x128,
+// 384 -> 128x384 (8 waves of 64x96, fp32 C only): ONE column tile for N <= 384, so the A operand is read - and, with the
+// exp loader, exponentiated - once instead of once per 128 columns. The 256x128 tile spends 32 exp per thread and 32-k
+// step on 16 MFMAs and is VALU-bound with that loader (430 TFLOP/s on the soft embedding); here it is 8 exp on 12 MFMAs.
+constexpr Tile TILES[4] = {{256, 256, 256, 256, 1.0}, {192, 256, 128, 512, 0.93}, {128, 128, 128, 768, 0.80},
+                           {384, 128, 384, 256, 0.90}};
 
 static inline bool plan(const cgn_gemm_bb_desc* d, bool smb, Tile* t_out, int* sk_out, int* kps_out) {
     const int K = d->K;
+    const bool expa = d->a_transform == CGN_ATRANS_EXP;
     // share of the block slots of the last round that hold a block
     auto fill = [&](long blocks, int slots) { return (double)blocks / ((double)cgn_cdiv(blocks, slots) * slots); };
     // splits along K that the caller's workspace can hold and that keep at least 512 k each
@@ -636,6 +645,13 @@ static inline bool plan(const cgn_gemm_bb_desc* d, bool smb, Tile* t_out, int* s
     for (const Tile& t : TILES) {
         if (d->force_tile && d->force_tile != t.code) continue;
         if (smb && t.code == 128) continue;  // (the fused epilogue is built for the 128x64 wave tile)
+        // the wide tile: fp32 results of at most one column tile; by request, or for the exp loader (see TILES)
+#ifndef CGN_BB_WIDE_EXPA
+#define CGN_BB_WIDE_EXPA 1  // (0: A/B builds, tools/build_variant.sh)
+#endif
+        const bool wide_expa = CGN_BB_WIDE_EXPA && expa;
+        if (t.code == 384 && (d->c_bf16 || smb || d->N > 384 || !(d->force_tile == 384 || wide_expa))) continue;
+        if (wide_expa && !d->force_tile && d->N <= 384 && t.code != 384 && !d->c_bf16) continue;
         const long tiles = (long)cgn_cdiv(d->M, t.bm) * cgn_cdiv(d->N, t.bn);
         const double pad = (double)d->M * d->N / ((double)tiles * t.bm * t.bn);
         for (int s = 1; s <= 16; ++s) {
@@ -666,7 +682,9 @@ static void launch(const Tile& t, dim3 grid, hipStream_t s, const Params& p) {
         hipLaunchKernelGGL((bb_kernel<4, 2, 2, 4, EXPA, SMB>), grid, dim3(512), 0, s, p);
     else if (t.code == 192)
         hipLaunchKernelGGL((bb_kernel<4, 2, 2, 2, EXPA, SMB>), grid, dim3(256), 0, s, p);
-    else if constexpr (!SMB)
+    else if (t.code == 384) {
+        if constexpr (!SMB) hipLaunchKernelGGL((bb_kernel<2, 3, 2, 4, EXPA, false>), grid, dim3(512), 0, s, p);
+    } else if constexpr (!SMB)
         hipLaunchKernelGGL((bb_kernel<2, 2, 2, 2, EXPA, false>), grid, dim3(256), 0, s, p);
 }
 
@@ -686,7 +704,8 @@ extern "C" int cgn_gemm_bb(void* stream, const cgn_gemm_bb_desc* d, void* ev_sta
     CGN_CHECK_ARG(d->A && d->B && d->C && d->K > 0 && d->K % 8 == 0);
     CGN_CHECK_ARG(d->lda % 8 == 0 && d->ldb % 8 == 0 && d->lda >= d->K && d->ldb >= d->K && d->ldc >= d->N);
     CGN_CHECK_ARG((uintptr_t)d->A % 16 == 0 && (uintptr_t)d->B % 16 == 0 && (uintptr_t)d->workspace % 16 == 0);
-    CGN_CHECK_ARG(d->force_tile == 0 || d->force_tile == 128 || d->force_tile == 192 || d->force_tile == 256);
+    CGN_CHECK_ARG(d->force_tile == 0 || d->force_tile == 128 || d->force_tile == 192 || d->force_tile == 256 ||
+                  d->force_tile == 384);
     CGN_CHECK_ARG(d->force_splitk >= 0 && d->force_splitk <= 16);
     CGN_CHECK_ARG(d->a_transform == CGN_ATRANS_NONE || (d->a_transform == CGN_ATRANS_EXP && d->a_row_param));
     CGN_CHECK_ARG(d->epilogue == CGN_EPI_LINEAR || d->epilogue == CGN_EPI_SOFTMAX_BWD);

@@ -370,7 +370,7 @@ def gemm_bb(a16, b16, out, *, K=None, alpha=1.0, beta=0.0, bias0=None, bias1=Non
             a_exp=None, softmax_bwd=None, c_t=None, dyn=None):
     """out[M,N] = alpha * a16 @ b16^T + beta*out + bias0 + bias1 with bfloat16 a16 [M, >=K], b16 [N, >=K] (unit k
     stride, row strides % 8 == 0, K % 8 == 0) and a float32 or bfloat16 out (cgn_gemm_bb). force_tile: 256 | 192 (the
-    256x128 tile) | 128. a_exp=(scale, lse): a16 := exp(a16*scale - lse[m]); softmax_bwd=dict(logits (bfloat16), lse,
+    256x128 tile) | 128 | 384 (128x384: float32 out, N <= 384). a_exp=(scale, lse): a16 := exp(a16*scale - lse[m]); softmax_bwd=dict(logits (bfloat16), lse,
     rowdot, target, inv_tau, ce_scale) with a bfloat16 out and the optional transposed copy c_t [N, >=M], as gemm()."""
     lib = _lib.load()
     for t, name in ((a16, "a16"), (b16, "b16")):

@@ -648,6 +648,9 @@ def test_cast_bf16_plain_history_axis_transposed_and_unaligned(dev):
     (1000, 300, 2048, dict(splitk=3)), (640, 900, 4096, dict(tile=256, splitk=4, bias=True, beta=1.0)),
     (128, 128, 64, dict(tile=128)), (1344, 2048, 512, dict(tile=128)), (1344, 2048, 512, dict(tile=256)),
     (260, 264, 8, dict(tile=256)), (130, 3000, 40, {}), (1, 1, 8, dict(tile=128)), (257, 129, 72, dict(tile=256)),
+    # the 128x384 tile (one column tile, fp32 result): full, ragged and narrow N, K tails, split with bias / beta
+    (300, 384, 328, dict(tile=384)), (1344, 300, 2000, dict(tile=384, splitk=5, bias=True, beta=1.0)),
+    (129, 130, 72, dict(tile=384)), (640, 304, 8, dict(tile=384, bias=True, beta=0.5, alpha=0.7)),
 ])
 def test_gemm_bb_against_fp64(dev, M, N, K, kw):
     """fp32 C: the fp64 product of the bf16 operands up to fp32 summation error (2e-6 of sum |a||b|), exact on small
@@ -706,6 +709,11 @@ def test_gemm_bb_refuses_what_it_cannot_read(dev):
         ops.gemm_bb(a, b, out.bfloat16(), K=64, beta=1.0)  # a bf16 result cannot be accumulated into
     with pytest.raises(RuntimeError):
         ops.gemm_bb(a, b, out, K=64, force_tile=64)
+    with pytest.raises(RuntimeError):
+        ops.gemm_bb(a, b, out.bfloat16(), K=64, force_tile=384)  # the 128x384 tile writes fp32 only
+    wide = torch.zeros(392, 72, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        ops.gemm_bb(a, wide, torch.zeros(64, 392, device=dev), K=64, force_tile=384)  # more than one column tile
 
 
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt"])
@@ -769,10 +777,12 @@ def test_gemm_bb_softmax_backward_and_exp_operand(dev, M, V, E, ldpad, tile):
     dout = torch.randn(M, E, generator=g).to(dev).bfloat16()
     # exp loader: softmax(L / tau) @ emb (B operand [N = E, K = V])
     if E >= 128:
-        out_emb = torch.full((M, E), float("nan"), device=dev)
-        ops.gemm_bb(logits if ldpad == 0 else L0, emb.t().contiguous(), out_emb, a_exp=(1.0 / tau, lse32),
-                    force_tile=tile if tile != 192 or True else 0)
-        assert _rel(out_emb, (P @ emb.double()).cpu()) < 1e-2
+        # (forced tile, then the planner's own choice: the 128x384 tile for a product of one column tile)
+        for ft in (tile, 0):
+            out_emb = torch.full((M, E), float("nan"), device=dev)
+            ops.gemm_bb(logits if ldpad == 0 else L0, emb.t().contiguous(), out_emb, a_exp=(1.0 / tau, lse32),
+                        force_tile=ft)
+            assert _rel(out_emb, (P @ emb.double()).cpu()) < 1e-2
     rowdot = torch.randn(M, generator=g).to(dev)
     ce_scale = 79.0 / tau / M
     ct_buf = torch.full((V, M + 8 + ldpad), float("nan"), device=dev, dtype=torch.bfloat16)
