@@ -27,6 +27,17 @@ __device__ __forceinline__ void quad_update(float& m, float& s, float q0, float 
     s += expf(q0 - m) + expf(q1 - m) + expf(q2 - m) + expf(q3 - m);
 }
 
+// the bf16-stored logits: v_exp_f32 (2^-21 relative) is far below the storage rounding; with expf's ~12 instructions
+// per element the one-read kernel was VALU-bound there (1 GB of bf16 logits at configs[3] shapes in 316 us = 3.3 TB/s)
+__device__ __forceinline__ void quad_update_fast(float& m, float& s, float q0, float q1, float q2, float q3) {
+    const float qm = fmaxf(fmaxf(q0, q1), fmaxf(q2, q3));
+    if (qm > m) {
+        s *= __expf(m - qm);
+        m = qm;
+    }
+    s += (__expf(q0 - m) + __expf(q1 - m)) + (__expf(q2 - m) + __expf(q3 - m));
+}
+
 __device__ __forceinline__ float bf16_at(const void* base, long i) {
     return __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(base)[i] << 16);
 }
@@ -48,17 +59,23 @@ __global__ __launch_bounds__(SM_NT) void softmax_nll_fwd_kernel(const void* __re
         if ((uintptr_t)xh % 16 == 0) {
             const int nv = V / 8;
             const u32x4_sm* xv = reinterpret_cast<const u32x4_sm*>(xh);
-            for (int i = threadIdx.x; i < nv; i += SM_NT) {
-                const u32x4_sm v = xv[i];
+            auto take = [&](const u32x4_sm v) {
                 float q[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     q[2 * j] = __builtin_bit_cast(float, v[j] << 16) * inv_tau;
                     q[2 * j + 1] = __builtin_bit_cast(float, v[j] & 0xffff0000u) * inv_tau;
                 }
-                quad_update(m, s, q[0], q[1], q[2], q[3]);
-                quad_update(m, s, q[4], q[5], q[6], q[7]);
+                quad_update_fast(m, s, q[0], q[1], q[2], q[3]);
+                quad_update_fast(m, s, q[4], q[5], q[6], q[7]);
+            };
+            int i = threadIdx.x;
+            for (; i + SM_NT < nv; i += 2 * SM_NT) {  // two loads in flight per thread
+                const u32x4_sm v0 = xv[i], v1 = xv[i + SM_NT];
+                take(v0);
+                take(v1);
             }
+            if (i < nv) take(xv[i]);
             for (int i = nv * 8 + threadIdx.x; i < V; i += SM_NT) online_update(m, s, bf16_at(xh, i) * inv_tau);
         } else {
             for (int i = threadIdx.x; i < V; i += SM_NT) online_update(m, s, bf16_at(xh, i) * inv_tau);
