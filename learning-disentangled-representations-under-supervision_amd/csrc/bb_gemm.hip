@@ -320,6 +320,10 @@ __global__ __launch_bounds__(64 * WVM * WVN, (WTM == 2 && WVM * WVN == 4 ? 3 : 2
         //      slab ahead), its sums two ds_read_b128; the 8 results leave as one 16-byte store to C and one
         //      ds_write_b128 into a bf16 image [32][72];
         //   3. the transposed copy reads that image down the columns (8 two-byte reads per 16-byte store to ct).
+        // (Where the transposed copy's 0.39 ms at configs[3] shapes go, measured with timing-only builds: the LDS reads
+        // cost nothing (stores left out: +9 us over the product without the copy); the same bytes stored row-major
+        // instead of as 64-byte column pieces: 1188 against 1272 us. It is the third GB of traffic itself, in a kernel
+        // whose 256x256 blocks do their memory phase after their matrix phase.)
         constexpr int RSF = 68, RSR = 72, WAVE_BYTES = 32 * RSF * 4 + 32 * RSR * 2;
         __syncthreads();  // every wave is done with the operand stages
         float* facc = reinterpret_cast<float*>(lds + wave * WAVE_BYTES);
