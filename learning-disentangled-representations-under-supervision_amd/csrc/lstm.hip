@@ -382,6 +382,8 @@ __device__ __forceinline__ void st_sc1(unsigned* p, unsigned v) {
 __device__ __forceinline__ long hx_off(int par, int KG, int kg, int B, int b) {  // element offset of (parity, k group, row)
     return ((long)(par * KG + kg) * B + b) * 8;
 }
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 2.f * fast_sigmoid(2.f * x) - 1.f; }
 // element offset of row b, k group kg (4 fp32) in the TILE-major fp32 scratch of the row-tiled kernels:
 // [parity][batch tile of 16 rows][KG4][16 rows][4] - with B = 256 rows the k groups of the layout above lie 4 KB apart
 // and a lane's successive loads 16 KB; here a wave's load is 1 KB of contiguous memory whatever B is
@@ -1001,12 +1003,24 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_fwd_rt_kernel(const FwdP
                     for (int wv = 0; wv < LSTM_NW; ++wv) v += red[wv][g * 4 + er][lane];
                     pre[g] = v + pre_x[rt][g] + pre_e[rt][g];
                 }
-                const float ig = cgn_sigmoid(pre[0]);
-                const float fg = cgn_sigmoid(pre[1]);
-                const float gg = tanhf(pre[2]);
-                const float og = cgn_sigmoid(pre[3]);
-                const float cn = fg * c_reg[rt] + ig * gg;
-                const float hn = og * tanhf(cn);
+                // X1 (the bf16 mode): v_exp_f32 / v_rcp_f32 forms, ~1e-7 absolute - far below the operands' rounding;
+                // expf, the division and tanhf are ~150 instructions per element and row tile on the step's chain
+                float ig, fg, gg, og, cn, hn;
+                if constexpr (XM == 1) {
+                    ig = fast_sigmoid(pre[0]);
+                    fg = fast_sigmoid(pre[1]);
+                    gg = fast_tanh(pre[2]);
+                    og = fast_sigmoid(pre[3]);
+                    cn = fg * c_reg[rt] + ig * gg;
+                    hn = og * fast_tanh(cn);
+                } else {
+                    ig = cgn_sigmoid(pre[0]);
+                    fg = cgn_sigmoid(pre[1]);
+                    gg = tanhf(pre[2]);
+                    og = cgn_sigmoid(pre[3]);
+                    cn = fg * c_reg[rt] + ig * gg;
+                    hn = og * tanhf(cn);
+                }
                 c_reg[rt] = cn;
                 float* go = sq.gates + ((long)eb * T + t) * 4 * H;
                 go[ej] = ig;
@@ -1201,7 +1215,7 @@ __global__ __launch_bounds__(LSTM_NT) void lstm_persist_bwd_rt_kernel(const BwdP
                 for (int wv = 0; wv < LSTM_NW; ++wv) dh += red[wv][er][lane];
                 if (step == 0) dh += seed[rt];
                 dh += dhx;
-                const float tc = tanhf(cout);
+                const float tc = XM == 1 ? fast_tanh(cout) : tanhf(cout);  // (X1: as in the forward kernel)
                 const float dc = dc_reg[rt] + dh * og * (1.f - tc * tc);
                 float* dg = sq.dgates + ((long)eb * T + t) * K;
                 const float d0 = dc * gg * ig * (1.f - ig), d1 = dc * cprev * fg * (1.f - fg);
