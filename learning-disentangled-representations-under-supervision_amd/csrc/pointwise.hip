@@ -317,29 +317,45 @@ __global__ __launch_bounds__(DH_NT) void disc_head_kernel(const float* __restric
     __shared__ float red[DH_NT / 64 + 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float ce_acc = 0.f, ent_acc = 0.f;
-    for (int b = wave; b < B; b += DH_NT / 64) {
-        float s0 = 0.f, s1 = 0.f;
+    // A wave takes its rows four at a time (B = 64: all of them): the loads of the four rows are issued together, so the
+    // kernel pays one L2 round trip per group instead of one per row (it is a latency chain on the discriminator's
+    // stream: 21 -> 13 us). Per row the sums are formed in the same order as before.
+    constexpr int RB = 4;
+    for (int bg = wave; bg < B; bg += RB * (DH_NT / 64)) {
+        float s0r[RB], s1r[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) s0r[r] = s1r[r] = 0.f;
         // batches of 8 chunks: all loads of a batch are issued (clamped addresses) before the first is consumed
         for (int f0 = 0; f0 < F; f0 += 512) {
-            float xv[8], mv[8], w0v[8], w1v[8];
+            float xv[RB][8], mv[RB][8], w0v[8], w1v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int f = f0 + u * 64 + lane;
                 const int fc = f < F ? f : 0;
-                xv[u] = feat[(long)b * ldf + fc];
-                mv[u] = mask ? mask[(long)b * F + fc] : 1.f;
                 w0v[u] = W[fc];
                 w1v[u] = W[F + fc];
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    const int b = min(bg + r * (DH_NT / 64), B - 1);
+                    xv[r][u] = feat[(long)b * ldf + fc];
+                    mv[r][u] = mask ? mask[(long)b * F + fc] : 1.f;
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float x = (f0 + u * 64 + lane < F) ? xv[u] * mv[u] : 0.f;
-                s0 += x * w0v[u];
-                s1 += x * w1v[u];
-            }
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float x = (f0 + u * 64 + lane < F) ? xv[r][u] * mv[r][u] : 0.f;
+                    s0r[r] += x * w0v[u];
+                    s1r[r] += x * w1v[u];
+                }
         }
-        s0 = wave_sum(s0) + bias[0];
-        s1 = wave_sum(s1) + bias[1];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+        const int b = bg + r * (DH_NT / 64);
+        if (b >= B) break;  // (wave-uniform)
+        const float s0 = wave_sum(s0r[r]) + bias[0];
+        const float s1 = wave_sum(s1r[r]) + bias[1];
         if (lane == 0) {
             const float mx = fmaxf(s0, s1);
             const float lse = mx + logf(expf(s0 - mx) + expf(s1 - mx));
@@ -364,6 +380,7 @@ __global__ __launch_bounds__(DH_NT) void disc_head_kernel(const float* __restric
                 dlogits[b * 2 + 1] = d1 / (float)B;
             }
         }
+        }
     }
     ce_acc = block_sum<DH_NT>(ce_acc, red);
     ent_acc = block_sum<DH_NT>(ent_acc, red);
@@ -384,10 +401,11 @@ __global__ __launch_bounds__(PW_NT) void disc_head_bwd_kernel(const float* __res
     if (f < F) {
         float a0 = 0.f, a1 = 0.f;
         const float w0 = W[f], w1 = W[F + f];
-        for (int b0 = 0; b0 < B; b0 += 8) {  // 8 rows of loads in flight (the walk was one L2 round trip per row)
-            float mk[8], xv[8], d0[8], d1[8];
+        constexpr int RBW = 16;  // rows of loads in flight (the walk was one L2 round trip per row; 8 rows: 20 us at B = 64)
+        for (int b0 = 0; b0 < B; b0 += RBW) {
+            float mk[RBW], xv[RBW], d0[RBW], d1[RBW];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < RBW; ++u) {
                 const int b = min(b0 + u, B - 1);
                 mk[u] = mask ? mask[(long)b * F + f] : 1.f;
                 xv[u] = feat[(long)b * ldf + f];
@@ -395,7 +413,7 @@ __global__ __launch_bounds__(PW_NT) void disc_head_bwd_kernel(const float* __res
                 d1[u] = dlogits[b * 2 + 1];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < RBW; ++u) {
                 if (b0 + u < B) {
                     const float x = xv[u] * mk[u];
                     a0 += d0[u] * x;
